@@ -1,0 +1,26 @@
+"""Shared pytest setup: marker registration + import paths.
+
+The product package mirrors the reference's layout, so it needs the same two
+roots on sys.path that the reference needs (<pkg> and <pkg>/src).
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "acoustic_locating_vq-vae_amd")
+for p in (ROOT, PKG, os.path.join(PKG, "src")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

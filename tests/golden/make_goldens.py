@@ -1,0 +1,239 @@
+"""Generate tests/golden/*.npz by running the REAL reference (build container only).
+
+Run:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 \
+      PYTHONPATH=/root/repo:/root/reference:/root/reference/src \
+      python3 /root/repo/tests/golden/make_goldens.py
+
+The fixtures are data only (inputs + expected outputs); weights and inputs come
+from ``oracle.vqvae_oracle.hashed_uniform`` (integer hash, bit-reproducible) so the
+big configs need not store them.  G6 (STFT) comes from the torch.stft restatement
+because torchaudio is absent -- it is marked parity-unpinned.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import vqvae_oracle as O
+from oracle import stft_oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def expand_aliases(p, num_layers):
+    out = {}
+    for k, v in p.items():
+        if "_layers.0." in k:
+            for r in range(num_layers):
+                out[k.replace("_layers.0.", "_layers.%d." % r)] = v
+        else:
+            out[k] = v
+    return out
+
+
+def top2(flat, codebook):
+    """(two smallest fp32 distances per row, argmin) -- argmin is torch.argmin
+    (lowest index on ties, what the reference calls); topk gives values only."""
+    d = O.vq_distances(flat, codebook)
+    v, _ = torch.topk(d, 2, dim=1, largest=False)
+    return v.numpy(), torch.argmin(d, dim=1).numpy()
+
+
+def sl(t, n=64):
+    f = t.detach().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy()
+
+
+def checksum(t):
+    f = t.detach().double().flatten()
+    return np.array([float(f.sum()), float(f.abs().sum()), float((f * f).sum())])
+
+
+def g1_tiny():
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    cfg = (7, 16, 4, 2, 8, 0.25, 16)
+    shapes = O.vqvae_param_shapes(7, 16, 4, 8, 16)
+    p = O.closed_form_params(shapes, codebook_scale=0.8)
+    model = ConvolutionalVQVAE(*cfg)
+    model.load_state_dict(expand_aliases(p, 2))
+    model.train()
+    x_raw = torch.from_numpy(O.hashed_uniform(2 * 7 * 13, 77, 2.0).reshape(2, 7, 13))
+    x = O.speech_preprocess(x_raw)
+    np.random.seed(5)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=False)
+    opt.zero_grad()
+    z = model._pre_vq_conv(model._encoder(x))
+    np.random.seed(5)
+    vq_loss, recon, perp = model(x)
+    recon_error = F.mse_loss(recon, x)
+    (recon_error + vq_loss).backward()
+    grads = {k: pp.grad.clone() for k, pp in model.named_parameters()}
+    opt.step()
+    after = {k: pp.detach().clone() for k, pp in model.named_parameters()}
+    np.random.seed(5)
+    src = O.jitter_source_index(13, 0.25)
+    with torch.no_grad():
+        _, q_st, _, enc = model.eval().get_latent_representation(x)
+    out = {"x_raw": x_raw.numpy(), "x": x.numpy(), "z": z.detach().numpy(), "idx": enc.argmax(1).numpy().astype(np.int64),
+           "q_st": q_st.numpy(), "vq_loss": vq_loss.detach().numpy(), "recon_error": recon_error.detach().numpy(),
+           "perplexity": perp.detach().numpy(), "recon": recon.detach().numpy(), "jitter_src": src,
+           "encodings": enc.numpy()}
+    for k, v in p.items():
+        out["param:" + k] = v.numpy()
+        out["grad:" + k] = grads[k].numpy()
+        out["after:" + k] = after[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "g1_tiny_vqvae.npz"), **out)
+    print("g1", float(perp), float(vq_loss), float(recon_error))
+
+
+def g2_vq():
+    from acoustic_locating_vq_vae.vq_vae.vector_quantizer import VectorQuantizer
+    out = {}
+    n, k, d = 2000, 1024, 128
+    x = torch.from_numpy(O.hashed_uniform(n * d, 11, 1.7).reshape(4, d, n // 4))  # (4,128,500): N = 2000 rows
+    regimes = {
+        "data": torch.from_numpy(O.hashed_uniform(k * d, 12, 1.7).reshape(k, d)),
+        "init": torch.from_numpy(O.hashed_uniform(k * d, 13, 1.0 / k).reshape(k, d)),
+    }
+    ties = torch.from_numpy(O.hashed_uniform(k * d, 14, 1.7).reshape(k, d)).clone()
+    ties[5] = ties[2]
+    ties[7] = ties[2]
+    ties[900] = ties[33]
+    regimes["ties"] = ties
+    out["x"] = x.numpy()
+    for name, cb in regimes.items():
+        vq = VectorQuantizer(k, d, 0.25)
+        with torch.no_grad():
+            vq._embedding.weight.copy_(cb)
+        xin = x.clone().requires_grad_(True)
+        loss, q_st, perp, enc = vq(xin)
+        g = torch.from_numpy(O.hashed_uniform(x.numel(), 15, 1.0).reshape(x.shape))
+        (loss + (q_st * g).sum()).backward()
+        idx = enc.argmax(1)
+        v, i = top2(x.reshape(-1, d), cb)
+        assert (i == idx.numpy()).all()
+        out[name + ":idx"] = idx.numpy().astype(np.int16)
+        out[name + ":top2_val"] = v
+        out[name + ":loss"] = loss.detach().numpy()
+        out[name + ":perplexity"] = perp.detach().numpy()
+        out[name + ":q_st_slice"] = sl(q_st, 256)
+        out[name + ":q_st_sum"] = checksum(q_st)
+        out[name + ":dx_slice"] = sl(xin.grad, 256)
+        out[name + ":dx_sum"] = checksum(xin.grad)
+        out[name + ":dE_slice"] = sl(vq._embedding.weight.grad, 256)
+        out[name + ":dE_sum"] = checksum(vq._embedding.weight.grad)
+        print("g2", name, float(perp), float(loss))
+    # rows mapped to duplicate codes must pick the lowest index
+    np.savez_compressed(os.path.join(HERE, "g2_vq.npz"), **out)
+
+
+def big(tag, cfg, shape, permuted, out_channels, use_jitter, cb_scale):
+    """cb_scale: codebook U(+-cb_scale), chosen ~1.5x std(z) so the argmin has data-scale margins."""
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    in_c, h, d, r, rh, beta, k = cfg
+    shapes = O.vqvae_param_shapes(in_c, h, d, rh, k, out_channels)
+    p = O.closed_form_params(shapes, codebook_scale=cb_scale, gain=GAIN)
+    model = ConvolutionalVQVAE(*cfg, use_jitter=use_jitter, out_channels=out_channels)
+    model.load_state_dict(expand_aliases(p, r))
+    model.train()
+    x_raw = torch.from_numpy(O.hashed_uniform(int(np.prod(shape)), 21, 2.0).reshape(shape))
+    x = O.speech_preprocess(x_raw)
+    if permuted:
+        x = x.permute(0, 2, 1)
+    if out_channels is None:
+        target = x
+    else:
+        tr = torch.from_numpy(O.hashed_uniform(shape[0] * x.shape[2], 22, 2.0).reshape(shape[0], x.shape[2]))
+        target = O.standardise(tr).unsqueeze(1)
+    z = model._pre_vq_conv(model._encoder(x)).detach()
+    np.random.seed(9)
+    vq_loss, recon, perp = model(x)
+    recon_error = F.mse_loss(recon, target)
+    (recon_error + vq_loss).backward()
+    cb = p["_vq._embedding.weight"]
+    v, i = top2(z.reshape(-1, d), cb)
+    out = {"idx": i.astype(np.int16), "top2_val": v,
+           "vq_loss": vq_loss.detach().numpy(), "recon_error": recon_error.detach().numpy(),
+           "perplexity": perp.detach().numpy(), "z_slice": sl(z), "z_sum": checksum(z),
+           "recon_slice": sl(recon), "recon_sum": checksum(recon), "z_std": np.array(float(z.std())),
+           "cb_scale": np.array(cb_scale), "gain": np.array(GAIN)}
+    for key, pp in model.named_parameters():
+        out["grad_slice:" + key] = sl(pp.grad)
+        out["grad_sum:" + key] = checksum(pp.grad)
+    np.savez_compressed(os.path.join(HERE, "g3_%s.npz" % tag), **out)
+    gap = (v[:, 1] - v[:, 0]) / np.abs(v[:, 0])
+    print("g3", tag, "perp", float(perp), "vq", float(vq_loss), "rec", float(recon_error), "zstd", float(z.std()),
+          "min rel gap", gap.min(), "n<1e-4", int((gap < 1e-4).sum()))
+
+
+def g3_echoed():
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
+    sp_cfg = (201, 1024, 128, 3, 1024, 0.25, 1024)
+    rir_cfg = (500, 1024, 64, 2, 64, 0.25, 1024)
+    sp_p = O.closed_form_params(O.vqvae_param_shapes(201, 1024, 128, 1024, 1024), codebook_scale=SPEECH_CB, gain=GAIN)
+    rir_p = O.closed_form_params(O.vqvae_param_shapes(500, 1024, 64, 64, 1024, 1), codebook_scale=RIR_CB, gain=GAIN)
+    sp = ConvolutionalVQVAE(*sp_cfg)
+    sp.load_state_dict(expand_aliases(sp_p, 3))
+    rir = ConvolutionalVQVAE(*rir_cfg, use_jitter=False, out_channels=1)
+    rir.load_state_dict(expand_aliases(rir_p, 2))
+    model = EchoedSpeechReconModel(rir, sp, 201, 1024, 2, 1024, True)
+    dec_p = O.closed_form_params(O.decoder_param_shapes(192, 201, 1024, 1024), gain=GAIN)
+    model._decoder.load_state_dict({k[len("_decoder."):]: v for k, v in expand_aliases(dec_p, 2).items()})
+    model.train()
+    shape = (2, 201, 500)
+    x = O.standardise(torch.from_numpy(O.hashed_uniform(int(np.prod(shape)), 21, 2.0).reshape(shape)).abs())
+    np.random.seed(9)
+    recon, sperp, rperp = model(x, x.permute(0, 2, 1))
+    err = F.mse_loss(recon, x)
+    err.backward()
+    out = {"recon_error": err.detach().numpy(), "speech_perplexity": sperp.detach().numpy(),
+           "rir_perplexity": rperp.detach().numpy(), "recon_slice": sl(recon), "recon_sum": checksum(recon),
+           "speech_cb_scale": np.array(SPEECH_CB), "rir_cb_scale": np.array(RIR_CB), "gain": np.array(GAIN)}
+    for key, pp in model._decoder.named_parameters():
+        out["grad_slice:_decoder." + key] = sl(pp.grad)
+        out["grad_sum:_decoder." + key] = checksum(pp.grad)
+    np.savez_compressed(os.path.join(HERE, "g3_echoed.npz"), **out)
+    print("g3 echoed", float(err), float(sperp), float(rperp))
+
+
+def g5_jitter():
+    from acoustic_locating_vq_vae.vq_vae.modules.jitter import Jitter
+    out = {}
+    for length in (13, 201, 500):
+        for seed in (0, 1):
+            q = torch.arange(length, dtype=torch.float32).view(1, 1, length).clone()
+            np.random.seed(seed)
+            res = Jitter(0.25)(q)
+            out["L%d_s%d" % (length, seed)] = res.view(-1).numpy().astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "g5_jitter.npz"), **out)
+    print("g5 ok")
+
+
+def g6_stft():
+    t = np.arange(4000, dtype=np.float64) / 16000.0
+    chirp = np.sin(2 * np.pi * (200.0 * t + 0.5 * 12000.0 * t * t)) * (0.6 + 0.4 * np.cos(2 * np.pi * 3 * t))
+    wave32 = torch.from_numpy(chirp.astype(np.float32)).view(1, -1)
+    p32 = stft_oracle.stft_power(wave32)
+    p64 = stft_oracle.stft_power(torch.from_numpy(chirp).view(1, -1))
+    direct = stft_oracle.stft_power_direct(chirp.reshape(1, -1))
+    assert np.allclose(direct, p64.numpy(), rtol=1e-9, atol=1e-12)
+    np.savez_compressed(os.path.join(HERE, "g6_stft_unpinned.npz"), wave=chirp, power_f32=p32.numpy(), power_f64=p64.numpy())
+    print("g6", p32.shape)
+
+
+GAIN = 0.5
+SPEECH_CB = 1.0
+RIR_CB = 1.0
+
+if __name__ == "__main__":
+    g1_tiny()
+    g2_vq()
+    big("speech", (201, 1024, 128, 3, 1024, 0.25, 1024), (2, 201, 500), False, None, True, SPEECH_CB)
+    big("rir", (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False, RIR_CB)
+    g3_echoed()
+    g5_jitter()
+    g6_stft()
