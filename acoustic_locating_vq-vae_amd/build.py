@@ -1,0 +1,64 @@
+"""Build libalvq.so (the C-ABI HIP library) in-tree for gfx950.
+
+    python build.py            # incremental
+    python build.py --force
+
+hipcc cross-compiles without a GPU.  Output: <this dir>/lib/libalvq.so (git-ignored, but it
+travels to the GPU box with the gpurun snapshot).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-Wno-unused-result", "-I", os.path.join(os.path.dirname(HERE), "include")]
+
+
+def _stamp(path):
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)) + ["../../include/alvq.h"]:
+        if f.endswith((".h", ".hip")):
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OUT, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
+    lib = os.path.join(OUT, "libalvq.so")
+    stamp_file = os.path.join(OBJ, "stamp")
+    stamp = _stamp(CSRC)
+    if not force and os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return lib
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+    def cc(src):
+        obj = os.path.join(OBJ, src[:-4] + ".o")
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        objs = list(ex.map(cc, srcs))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

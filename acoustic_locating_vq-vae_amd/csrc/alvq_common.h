@@ -1,0 +1,53 @@
+// Shared host/device helpers for libalvq (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/alvq.h"
+
+namespace alvq {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return ALVQ_OK;
+}
+
+#define ALVQ_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      alvq::set_error(__VA_ARGS__);    \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+constexpr int kWave = 64;  // CDNA wavefront
+constexpr int kNumXcd = 8;
+
+// Bijective XCD-aware remap (guide T1): hardware deals consecutive workgroup ids round-robin over the
+// 8 XCDs; give each XCD a contiguous run of logical tile ids so neighbours share operands in its L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n / kNumXcd, r = n % kNumXcd;
+  const int xcd = id % kNumXcd, local = id / kNumXcd;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace alvq

@@ -1,0 +1,326 @@
+// Vector-quantiser kernels (reference: vq_vae/vector_quantizer.py:29-58).
+//
+// Rows are D-float chunks of the contiguous (B,D,L) activation buffer in memory order (no permute, :32),
+// so every row read/write below is a fully coalesced contiguous segment.
+//
+// argmin: pairwise-L2 as an exact-fp32 MFMA GEMM (x . E^T) with the x row-block stationary in LDS and the
+// codebook streamed through LDS in (128 codes x 32 dims) tiles -- no default codebook fits 160 KiB
+// (1024x128 fp32 = 512 KiB), so "LDS-resident" means tiled.  The distance is formed exactly as the
+// reference does, d = fl(fl(|x|^2 + |e|^2) - 2 x.e), and reduced on (d, k) with lowest k on ties
+// (torch.argmin semantics), first along each lane's own columns, then across the 16 lanes that share a row.
+#include "alvq_common.h"
+
+namespace alvq {
+
+constexpr int VQ_RB = 64;    // rows per workgroup (16 per wave)
+constexpr int VQ_CT = 128;   // codes per tile
+constexpr int VQ_DK = 32;    // dims per staged chunk
+constexpr int VQ_ES = 34;    // Es row stride: 34*li mod 32 = 2*li -> conflict-free with kq in {0,1}
+constexpr int VQ_PARTIALS = 1024;
+
+__host__ __device__ constexpr int vq_pad32(int x, int r) { return x + ((r - x % 32) + 32) % 32; }
+
+// out[r] = sum_d x[r][d]^2, one wave per row, fixed order.
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* x, float* out, long rows, int D) {
+  const int lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float v = x[r * D + d];
+      s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+  }
+}
+
+struct ArgminArgs {
+  const float* x;
+  const float* e;
+  const float* xn;  // |x_n|^2
+  const float* en;  // |e_k|^2
+  int64_t* idx;
+  float* min_dist;
+  long N;
+  int K, D, Dp, XSTR;
+};
+
+__global__ __launch_bounds__(256, 2) void vq_argmin_f32_kernel(ArgminArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                          // [VQ_RB][XSTR]
+  float* Es = smem + VQ_RB * a.XSTR;         // [VQ_CT][VQ_ES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const long r0 = (long)blockIdx.x * VQ_RB;
+  const int D = a.D, K = a.K, XSTR = a.XSTR;
+
+  // stage the stationary x block (zero padded to Dp columns / missing rows)
+  for (int e = tid; e < VQ_RB * a.Dp; e += 256) {
+    const int r = e / a.Dp, d = e - r * a.Dp;
+    const long row = r0 + r;
+    Xs[r * XSTR + d] = (row < a.N && d < D) ? a.x[row * D + d] : 0.f;
+  }
+
+  float xn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long row = r0 + wave * 16 + kq * 4 + r;
+    xn[r] = row < a.N ? a.xn[row] : 0.f;
+  }
+  float best[4];
+  int bidx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    best[r] = __builtin_inff();
+    bidx[r] = 0x7fffffff;
+  }
+
+  // codebook staging: 128 codes x 32 dims = 4096 floats -> 16 per thread; thread -> (code = e/32, d = e%32)
+  const int ecol = tid & 31, erow0 = tid >> 5;  // rows erow0 + 8*i
+  float er[16];
+  auto load_e = [&](int k0, int d0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = k0 + erow0 + 8 * i, d = d0 + ecol;
+      er[i] = (k < K && d < D) ? a.e[(long)k * D + d] : 0.f;
+    }
+  };
+  auto store_e = [&]() {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Es[(erow0 + 8 * i) * VQ_ES + ecol] = er[i];
+  };
+
+  const int nd = a.Dp / VQ_DK;
+  const int nkt = (K + VQ_CT - 1) / VQ_CT;
+  const int total = nkt * nd;
+  load_e(0, 0);
+  store_e();
+  __syncthreads();
+  f32x4 acc[8];
+  for (int it = 0; it < total; ++it) {
+    const int kt = it / nd, dc = it - kt * nd;
+    if (dc == 0) {
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (it + 1 < total) {
+      const int kt2 = (it + 1) / nd, dc2 = (it + 1) - kt2 * nd;
+      load_e(kt2 * VQ_CT, dc2 * VQ_DK);
+    }
+#pragma unroll
+    for (int s = 0; s < VQ_DK / 4; ++s) {
+      const float af = Xs[(wave * 16 + li) * XSTR + dc * VQ_DK + s * 4 + kq];
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        const float bf = Es[(ni * 16 + li) * VQ_ES + s * 4 + kq];
+        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[ni], 0, 0, 0);
+      }
+    }
+    if (dc == nd - 1) {
+      // distances for this code tile: D[row = kq*4 + r][col = li]
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        const int k = kt * VQ_CT + ni * 16 + li;
+        if (k < K) {
+          const float bn = a.en[k];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = (xn[r] + bn) - 2.0f * acc[ni][r];
+            if (d < best[r]) {
+              best[r] = d;
+              bidx[r] = k;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (it + 1 < total) {
+      store_e();
+      __syncthreads();
+    }
+  }
+
+  // reduce over the 16 lanes (li) that hold different columns of the same rows
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d2 = __shfl_xor(best[r], o, 64);
+      const int k2 = __shfl_xor(bidx[r], o, 64);
+      if (d2 < best[r] || (d2 == best[r] && k2 < bidx[r])) {
+        best[r] = d2;
+        bidx[r] = k2;
+      }
+    }
+  }
+  if (li == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = r0 + wave * 16 + kq * 4 + r;
+      if (row < a.N) {
+        a.idx[row] = (int64_t)(bidx[r] == 0x7fffffff ? 0 : bidx[r]);
+        if (a.min_dist) a.min_dist[row] = best[r];
+      }
+    }
+  }
+}
+
+// q_st = x + (E[idx] - x); per-workgroup partial of sum (E[idx]-x)^2; histogram of idx.
+__global__ __launch_bounds__(256) void vq_gather_loss_kernel(const float* x, const float* e, const int64_t* idx,
+                                                             float* q_st, float* partials, int32_t* hist, long N, int K,
+                                                             int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s = 0.f;
+  for (long r = (long)blockIdx.x * 4 + wave; r < N; r += (long)gridDim.x * 4) {
+    const long k = idx[r];
+    for (int d = lane; d < D; d += 64) {
+      const float xv = x[r * D + d];
+      const float diff = e[k * D + d] - xv;
+      q_st[r * D + d] = xv + diff;
+      s += diff * diff;
+    }
+    if (lane == 0 && hist) atomicAdd(&hist[k], 1);
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void vq_finalize_kernel(const float* partials, int nparts, const int32_t* hist,
+                                                          float* out, long N, int K, int D, float beta) {
+  __shared__ float red[256];
+  const int t = threadIdx.x;
+  float s = 0.f;
+  for (int i = t; i < nparts; i += 256) s += partials[i];
+  red[t] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  const float sq = red[0];
+  __syncthreads();
+  float h = 0.f;
+  for (int k = t; k < K; k += 256) {
+    const float p = (float)hist[k] / (float)N;
+    h += p * logf(p + 1e-10f);
+  }
+  red[t] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const float m = sq / (float)((double)N * (double)D);
+    out[0] = m + beta * m;  // q_latent + beta * e_latent, both equal m in value (:46-52)
+    out[1] = expf(-red[0]);
+  }
+}
+
+__global__ __launch_bounds__(256) void vq_backward_kernel(const float* g, const float* grad_loss, const float* x,
+                                                          const float* e, const int64_t* idx, float* dx, float* dE,
+                                                          long N, int K, int D, float cx, float ce) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float gl = grad_loss ? grad_loss[0] : 1.f;
+  const float sx = gl * cx, se = gl * ce;
+  for (long r = (long)blockIdx.x * 4 + wave; r < N; r += (long)gridDim.x * 4) {
+    const long k = idx[r];
+    for (int d = lane; d < D; d += 64) {
+      const float xv = x[r * D + d];
+      const float diff = e[k * D + d] - xv;  // q - x
+      if (dx) dx[r * D + d] = (g ? g[r * D + d] : 0.f) - sx * diff;
+      if (dE) atomicAdd(&dE[k * D + d], se * diff);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* idx, float* enc, long N, int K) {
+  const long total = N * (long)K;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / K;
+    const int k = (int)(e - r * K);
+    enc[e] = (idx[r] == k) ? 1.f : 0.f;
+  }
+}
+
+}  // namespace alvq
+
+using namespace alvq;
+
+static int grid_for(long work_items, int per_block) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int64_t alvq_vq_argmin_workspace_bytes(int64_t N, int K, int D) {
+  if (N <= 0 || K <= 0 || D <= 0) return -1;
+  return (int64_t)(N + K) * (int64_t)sizeof(float);
+}
+
+extern "C" int alvq_vq_argmin_f32(const float* x, const float* codebook, int64_t* idx, float* min_dist,
+                                  void* workspace, int64_t N, int K, int D, void* stream) {
+  ALVQ_REQUIRE(x && codebook && idx && workspace, ALVQ_EINVAL, "alvq_vq_argmin_f32: null pointer");
+  ALVQ_REQUIRE(N > 0 && K > 0 && D > 0, ALVQ_EINVAL, "alvq_vq_argmin_f32: bad dims N=%ld K=%d D=%d", (long)N, K, D);
+  ALVQ_REQUIRE(D <= 512, ALVQ_EUNSUPPORTED, "alvq_vq_argmin_f32: D=%d > 512 does not fit the stationary LDS tile", D);
+  ALVQ_REQUIRE(N / VQ_RB < (1L << 31) - 2, ALVQ_EUNSUPPORTED, "alvq_vq_argmin_f32: N too large");
+  hipStream_t s = (hipStream_t)stream;
+  float* xn = (float*)workspace;
+  float* en = xn + N;
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_for(N, 4)), dim3(256), 0, s, x, xn, (long)N, D);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid_for(K, 4)), dim3(256), 0, s, codebook, en, (long)K, D);
+  const int Dp = (D + VQ_DK - 1) / VQ_DK * VQ_DK;
+  const int XSTR = vq_pad32(Dp, 2);
+  ArgminArgs a{x, codebook, xn, en, idx, min_dist, (long)N, K, D, Dp, XSTR};
+  const size_t lds = (size_t)(VQ_RB * XSTR + VQ_CT * VQ_ES) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(vq_argmin_f32_kernel, dim3((unsigned)((N + VQ_RB - 1) / VQ_RB)), dim3(256), lds, s, a);
+  return check_launch("alvq_vq_argmin_f32");
+}
+
+extern "C" int alvq_vq_gather_loss_f32(const float* x, const float* codebook, const int64_t* idx, float* q_st,
+                                       float* sq_partials, int32_t* hist, int64_t N, int K, int D, void* stream) {
+  ALVQ_REQUIRE(x && codebook && idx && q_st && sq_partials, ALVQ_EINVAL, "alvq_vq_gather_loss_f32: null pointer");
+  ALVQ_REQUIRE(N > 0 && K > 0 && D > 0, ALVQ_EINVAL, "alvq_vq_gather_loss_f32: bad dims");
+  hipLaunchKernelGGL(vq_gather_loss_kernel, dim3(VQ_PARTIALS), dim3(256), 0, (hipStream_t)stream, x, codebook, idx,
+                     q_st, sq_partials, hist, (long)N, K, D);
+  return check_launch("alvq_vq_gather_loss_f32");
+}
+
+extern "C" int alvq_vq_finalize_f32(const float* sq_partials, const int32_t* hist, float* out, int64_t N, int K, int D,
+                                    float beta, void* stream) {
+  ALVQ_REQUIRE(sq_partials && hist && out, ALVQ_EINVAL, "alvq_vq_finalize_f32: null pointer");
+  ALVQ_REQUIRE(N > 0 && K > 0 && D > 0, ALVQ_EINVAL, "alvq_vq_finalize_f32: bad dims");
+  hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sq_partials, VQ_PARTIALS, hist,
+                     out, (long)N, K, D, beta);
+  return check_launch("alvq_vq_finalize_f32");
+}
+
+extern "C" int alvq_vq_backward_f32(const float* g, const float* grad_loss, const float* x, const float* codebook,
+                                    const int64_t* idx, float* dx, float* dE, int64_t N, int K, int D, float beta,
+                                    void* stream) {
+  ALVQ_REQUIRE(x && codebook && idx && (dx || dE), ALVQ_EINVAL, "alvq_vq_backward_f32: null pointer");
+  ALVQ_REQUIRE(N > 0 && K > 0 && D > 0, ALVQ_EINVAL, "alvq_vq_backward_f32: bad dims");
+  const double nd = (double)N * (double)D;
+  hipLaunchKernelGGL(vq_backward_kernel, dim3(grid_for(N, 4)), dim3(256), 0, (hipStream_t)stream, g, grad_loss, x,
+                     codebook, idx, dx, dE, (long)N, K, D, (float)(2.0 * beta / nd), (float)(2.0 / nd));
+  return check_launch("alvq_vq_backward_f32");
+}
+
+extern "C" int alvq_onehot_f32(const int64_t* idx, float* encodings, int64_t N, int K, void* stream) {
+  ALVQ_REQUIRE(idx && encodings, ALVQ_EINVAL, "alvq_onehot_f32: null pointer");
+  ALVQ_REQUIRE(N > 0 && K > 0, ALVQ_EINVAL, "alvq_onehot_f32: bad dims");
+  hipLaunchKernelGGL(onehot_kernel, dim3(grid_for(N * (long)K, 256 * 8)), dim3(256), 0, (hipStream_t)stream, idx,
+                     encodings, (long)N, K);
+  return check_launch("alvq_onehot_f32");
+}

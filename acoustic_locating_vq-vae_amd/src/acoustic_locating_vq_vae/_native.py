@@ -1,0 +1,273 @@
+"""ctypes binding of libalvq.so (include/alvq.h) -- the only door from Python to the HIP kernels.
+
+PyTorch is used for device memory and streams only: every function here takes torch CUDA(=HIP) tensors,
+checks shape/dtype/contiguity on the host, and passes raw ``data_ptr()``s plus the current HIP stream to
+the C ABI.  There is no CPU fallback: if the library is missing or a tensor is not on the GPU the call
+raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_LIB = None
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT_LIB = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libalvq.so"))
+
+W_OIK = 0
+W_IOK = 1
+VQ_PARTIALS = 1024
+EW_PARTIALS = 1024
+
+_c_void_p = ctypes.c_void_p
+_i32 = ctypes.c_int
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
+
+_SIGNATURES = {
+    "alvq_version": (ctypes.c_char_p, []),
+    "alvq_last_error": (ctypes.c_char_p, []),
+    "alvq_conv1d_f32": (_i32, [_c_void_p] * 9 + [_i32] * 7 + [_c_void_p]),
+    "alvq_conv1d_wgrad_workspace_bytes": (_i64, [_i32] * 5),
+    "alvq_conv1d_wgrad_f32": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
+    "alvq_vq_argmin_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "alvq_vq_argmin_f32": (_i32, [_c_void_p] * 5 + [_i64, _i32, _i32, _c_void_p]),
+    "alvq_vq_gather_loss_f32": (_i32, [_c_void_p] * 6 + [_i64, _i32, _i32, _c_void_p]),
+    "alvq_vq_finalize_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _i32, _f32, _c_void_p]),
+    "alvq_vq_backward_f32": (_i32, [_c_void_p] * 7 + [_i64, _i32, _i32, _f32, _c_void_p]),
+    "alvq_onehot_f32": (_i32, [_c_void_p, _c_void_p, _i64, _i32, _c_void_p]),
+    "alvq_jitter_gather_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _i32, _c_void_p]),
+    "alvq_standardise_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_mse_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p]),
+    "alvq_mse_backward_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p]),
+    "alvq_add_f32": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
+    "alvq_transpose_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
+    "alvq_adam_f32": (_i32, [_c_void_p] * 4 + [_i64, _i32, _f32, _f32, _f32, _f32, _f32, _c_void_p]),
+    "alvq_stft_power_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib_path():
+    return os.environ.get("ALVQ_LIB", _DEFAULT_LIB)
+
+
+def lib():
+    """Open libalvq.so once per process (module-global, so nn.Modules stay picklable)."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "libalvq.so not found at %s -- build it with `python acoustic_locating_vq-vae_amd/build.py` "
+                "(there is no CPU fallback for the HIP path)" % path)
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def version():
+    return lib().alvq_version().decode()
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError("%s failed (rc=%d): %s" % (name, rc, lib().alvq_last_error().decode()))
+
+
+def _ptr(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s); the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ----------------------------------------------------------------------------------------------- conv
+def conv1d(x, w, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, w_layout=W_OIK,
+           want_y2=False):
+    """Fused conv (see alvq_conv1d_f32).  x (B,C,L); w (M,C,KW) for W_OIK or (C,M,KW) for W_IOK.
+    Returns y or (y, y2)."""
+    B, C, L = x.shape
+    if w_layout == W_OIK:
+        M, Cw, KW = w.shape
+    else:
+        Cw, M, KW = w.shape
+    if Cw != C:
+        raise RuntimeError("conv1d: weight expects %d input channels, x has %d" % (Cw, C))
+    y = torch.empty((B, M, L), device=x.device, dtype=torch.float32)
+    y2 = torch.empty_like(y) if post is not None else None
+    for t, nm in ((skip1, "skip1"), (skip2, "skip2"), (mask, "mask"), (post, "post")):
+        if t is not None and tuple(t.shape) != (B, M, L):
+            raise RuntimeError("conv1d: %s has shape %s, expected %s" % (nm, tuple(t.shape), (B, M, L)))
+    if bias is not None and bias.numel() != M:
+        raise RuntimeError("conv1d: bias has %d elements, expected %d" % (bias.numel(), M))
+    rc = lib().alvq_conv1d_f32(_ptr(x, name="x"), _ptr(w, name="w"), _ptr(bias, name="bias"), _ptr(skip1, name="skip1"),
+                               _ptr(skip2, name="skip2"), _ptr(mask, name="mask"), _ptr(post, name="post"),
+                               _ptr(y), _ptr(y2), B, C, M, L, KW, w_layout, int(bool(relu)), _stream())
+    _check(rc, "alvq_conv1d_f32")
+    return (y, y2) if post is not None else y
+
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only scratch per device (caller-owned from the library's point of view)."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _WS[key] = buf
+    return buf
+
+
+def conv1d_wgrad(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, dbias_out=None, accumulate=False):
+    """dw (and dbias) of the conv whose input was x (B,C,L) and output-grad is dy (B,M,L)."""
+    B, C, L = x.shape
+    Bd, M, Ld = dy.shape
+    if (Bd, Ld) != (B, L):
+        raise RuntimeError("conv1d_wgrad: dy %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    shape = (M, C, KW) if w_layout == W_OIK else (C, M, KW)
+    if dw_out is None:
+        dw_out = torch.empty(shape, device=x.device, dtype=torch.float32)
+        accumulate = False
+    elif tuple(dw_out.shape) != shape:
+        raise RuntimeError("conv1d_wgrad: dw_out has shape %s, expected %s" % (tuple(dw_out.shape), shape))
+    if want_bias and dbias_out is None:
+        dbias_out = torch.empty((M,), device=x.device, dtype=torch.float32)
+    nbytes = lib().alvq_conv1d_wgrad_workspace_bytes(B, C, M, L, KW)
+    if nbytes < 0:
+        raise RuntimeError("conv1d_wgrad: unsupported shape")
+    ws = _workspace(nbytes, x.device)
+    rc = lib().alvq_conv1d_wgrad_f32(_ptr(dy, name="dy"), _ptr(x, name="x"), _ptr(dw_out, name="dw"),
+                                     _ptr(dbias_out, name="dbias") if want_bias else None, ws.data_ptr(),
+                                     B, C, M, L, KW, w_layout, int(bool(accumulate)), _stream())
+    _check(rc, "alvq_conv1d_wgrad_f32")
+    return (dw_out, dbias_out) if want_bias else dw_out
+
+
+# ----------------------------------------------------------------------------------------------- VQ
+def vq_argmin(flat, codebook, want_dist=False):
+    N, D = flat.shape
+    K, Dc = codebook.shape
+    if D != Dc:
+        raise RuntimeError("vq_argmin: row width %d != codebook dim %d" % (D, Dc))
+    idx = torch.empty((N,), device=flat.device, dtype=torch.int64)
+    dist = torch.empty((N,), device=flat.device, dtype=torch.float32) if want_dist else None
+    ws = _workspace(lib().alvq_vq_argmin_workspace_bytes(N, K, D), flat.device)
+    rc = lib().alvq_vq_argmin_f32(_ptr(flat, name="x"), _ptr(codebook, name="codebook"), idx.data_ptr(),
+                                  _ptr(dist), ws.data_ptr(), N, K, D, _stream())
+    _check(rc, "alvq_vq_argmin_f32")
+    return (idx, dist) if want_dist else idx
+
+
+def vq_gather_loss(flat, codebook, idx, beta):
+    """-> (q_st (N,D), out[2] = (loss, perplexity))."""
+    N, D = flat.shape
+    K = codebook.shape[0]
+    q_st = torch.empty_like(flat)
+    partials = torch.empty((VQ_PARTIALS,), device=flat.device, dtype=torch.float32)
+    hist = torch.zeros((K,), device=flat.device, dtype=torch.int32)
+    out = torch.empty((2,), device=flat.device, dtype=torch.float32)
+    L = lib()
+    _check(L.alvq_vq_gather_loss_f32(_ptr(flat, name="x"), _ptr(codebook, name="codebook"),
+                                     _ptr(idx, torch.int64, "idx"), _ptr(q_st), _ptr(partials),
+                                     _ptr(hist, torch.int32), N, K, D, _stream()), "alvq_vq_gather_loss_f32")
+    _check(L.alvq_vq_finalize_f32(_ptr(partials), _ptr(hist, torch.int32), _ptr(out), N, K, D, float(beta), _stream()),
+           "alvq_vq_finalize_f32")
+    return q_st, out
+
+
+def vq_backward(g, grad_loss, flat, codebook, idx, beta, want_dx=True, want_dE=True):
+    N, D = flat.shape
+    K = codebook.shape[0]
+    dx = torch.empty_like(flat) if want_dx else None
+    dE = torch.zeros_like(codebook) if want_dE else None
+    _check(lib().alvq_vq_backward_f32(_ptr(g, name="g"), _ptr(grad_loss, name="grad_loss"), _ptr(flat, name="x"),
+                                      _ptr(codebook, name="codebook"), _ptr(idx, torch.int64, "idx"), _ptr(dx), _ptr(dE),
+                                      N, K, D, float(beta), _stream()), "alvq_vq_backward_f32")
+    return dx, dE
+
+
+def onehot(idx, K):
+    N = idx.numel()
+    enc = torch.empty((N, K), device=idx.device, dtype=torch.float32)
+    _check(lib().alvq_onehot_f32(_ptr(idx, torch.int64, "idx"), _ptr(enc), N, K, _stream()), "alvq_onehot_f32")
+    return enc
+
+
+# ----------------------------------------------------------------------------------------------- misc
+def jitter_gather(x, src, backward=False):
+    """x (B,C,L) contiguous, src int32[L] on device."""
+    L = x.shape[-1]
+    y = torch.empty_like(x)
+    _check(lib().alvq_jitter_gather_f32(_ptr(x, name="x"), _ptr(src, torch.int32, "src"), _ptr(y), x.numel() // L, L,
+                                        int(bool(backward)), _stream()), "alvq_jitter_gather_f32")
+    return y
+
+
+def standardise(x, take_abs=False):
+    B, C, L = x.shape
+    y = torch.empty_like(x)
+    _check(lib().alvq_standardise_f32(_ptr(x, name="x"), _ptr(y), B, C, L, int(bool(take_abs)), _stream()),
+           "alvq_standardise_f32")
+    return y
+
+
+def mse(a, b):
+    if a.shape != b.shape:
+        raise RuntimeError("mse: shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    loss = torch.empty((1,), device=a.device, dtype=torch.float32)
+    ws = torch.empty((EW_PARTIALS,), device=a.device, dtype=torch.float32)
+    _check(lib().alvq_mse_f32(_ptr(a, name="a"), _ptr(b, name="b"), _ptr(loss), _ptr(ws), a.numel(), _stream()), "alvq_mse_f32")
+    return loss
+
+
+def mse_backward(a, b, grad_loss):
+    grad = torch.empty_like(a)
+    _check(lib().alvq_mse_backward_f32(_ptr(a, name="a"), _ptr(b, name="b"), _ptr(grad_loss, name="grad_loss"), _ptr(grad),
+                                       a.numel(), _stream()), "alvq_mse_backward_f32")
+    return grad
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    _check(lib().alvq_add_f32(_ptr(a, name="a"), _ptr(b, name="b"), _ptr(out), a.numel(), _stream()), "alvq_add_f32")
+    return out
+
+
+def transpose12(x):
+    """(B,R,C) -> (B,C,R) dense."""
+    B, R, C = x.shape
+    y = torch.empty((B, C, R), device=x.device, dtype=torch.float32)
+    _check(lib().alvq_transpose_f32(_ptr(x, name="x"), _ptr(y), B, R, C, _stream()), "alvq_transpose_f32")
+    return y
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _check(lib().alvq_adam_f32(_ptr(param, name="param"), _ptr(grad, name="grad"), _ptr(exp_avg, name="exp_avg"),
+                               _ptr(exp_avg_sq, name="exp_avg_sq"), param.numel(), int(step), float(lr), float(beta1),
+                               float(beta2), float(eps), float(grad_scale), _stream()), "alvq_adam_f32")
+
+
+def stft_power(wave, n_fft=400, hop=160):
+    B, S = wave.shape
+    power = torch.empty((B, n_fft // 2 + 1, 1 + S // hop), device=wave.device, dtype=torch.float32)
+    _check(lib().alvq_stft_power_f32(_ptr(wave, name="wave"), _ptr(power), B, S, n_fft, hop, _stream()), "alvq_stft_power_f32")
+    return power

@@ -1,0 +1,151 @@
+/*
+ * alvq.h -- C ABI of libalvq.so: the MI355X (gfx950) kernels behind the VQ-VAE
+ * train-step hot path of guy3540/Acoustic_Locating_VQ-VAE.
+ *
+ * The reference has no FFI layer: its operator API for this path is the
+ * torch.nn.Module surface of src/acoustic_locating_vq_vae/vq_vae/ (SURVEY 8b), and
+ * the ATen ops those modules call.  Each entry point below replaces one ATen op
+ * call site (cited as file:line into /root/reference/src/acoustic_locating_vq_vae/).
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless noted;
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library
+ *     never allocates, frees or retains device memory;
+ *   - launches are asynchronous on the caller's `stream` (a hipStream_t passed as
+ *     void*); no host synchronisation inside, so calls are graph-capturable;
+ *   - return 0 on success; a negative ALVQ_E* for arguments rejected before any
+ *     launch; a positive value is the hipError_t of a failed launch.
+ *     alvq_last_error() returns a thread-local message for the last failure;
+ *   - tensors are dense row-major fp32 unless the name says otherwise
+ *     ("_bf16": storage is bfloat16, accumulation is always fp32).
+ */
+#ifndef ALVQ_H
+#define ALVQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALVQ_OK 0
+#define ALVQ_EINVAL (-1)      /* bad pointer / dimension                        */
+#define ALVQ_EUNSUPPORTED (-2) /* shape or flag combination not implemented      */
+
+/* weight layouts for the conv family */
+#define ALVQ_W_OIK 0 /* w[M][C][KW]: nn.Conv1d weight used forward, or ConvTranspose1d weight used for its data-grad */
+#define ALVQ_W_IOK 1 /* w[C][M][KW] read flipped+transposed: nn.ConvTranspose1d forward, or nn.Conv1d data-grad       */
+
+/* storage dtypes */
+#define ALVQ_F32 0
+#define ALVQ_BF16 1
+
+const char* alvq_version(void);
+const char* alvq_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1-D convolution, stride 1, "same" padding, KW in {1,3}:  im2col-free implicit GEMM on MFMA.
+ *
+ *   acc[b,m,l] = sum_c sum_t A_t[m,c] * x[b,c,l+t-(KW-1)/2]           (zero outside [0,L))
+ *   A_t[m,c]   = w[m][c][t]            (ALVQ_W_OIK)
+ *              = w[c][m][KW-1-t]       (ALVQ_W_IOK)
+ *   v = acc (+ bias[m]) (+ skip1[b,m,l]) (+ skip2[b,m,l]);  if relu: v = max(v,0);
+ *   if mask: v = mask[b,m,l] > 0 ? v : 0;   y = v;   if y2: y2 = v + post[b,m,l]
+ *
+ * x is (B,C,L), y/skip1/skip2/mask/post/y2 are (B,M,L), all contiguous.  Optional pointers may be NULL.
+ * Replaces: nn.Conv1d forward (vq_vae/convolutional_encoder.py:17-23,40; convolutional_vq_vae.py:32-37,95;
+ * deconvolutional_decoder.py:19-25,69; modules/residual.py:37-54), nn.ConvTranspose1d forward
+ * (deconvolutional_decoder.py:35-59,73-77), F.relu / nn.ReLU(True) (residual.py:36,47;
+ * residual_stack.py:46), the residual and encoder skip adds (residual.py:66; convolutional_encoder.py:42),
+ * and -- through autograd -- the data-gradient of each of those with the ReLU-backward mask fused.
+ * ---------------------------------------------------------------------------------------------- */
+int alvq_conv1d_f32(const float* x, const float* w, const float* bias,
+                    const float* skip1, const float* skip2, const float* mask, const float* post,
+                    float* y, float* y2,
+                    int B, int C, int M, int L, int KW, int w_layout, int relu, void* stream);
+
+/* Weight gradient of the same convolution, split over the batch*length reduction:
+ *   dw_t[m,c] = sum_b sum_l dy[b,m,l] * x[b,c,l+t-(KW-1)/2]
+ * written as dw[m][c][t] (ALVQ_W_OIK) or dw[c][m][KW-1-t] (ALVQ_W_IOK, with dy/x roles as the caller passes them).
+ * `workspace` must hold alvq_conv1d_wgrad_workspace_bytes(...) bytes; partial sums are reduced in a fixed
+ * order (bitwise reproducible).  accumulate!=0 adds into dw (shared residual weights, residual_stack.py:40-41).
+ * If dbias != NULL also dbias[m] (+)= sum_b sum_l dy[b,m,l].
+ * Replaces: autograd's convolution_backward weight/bias grads for every call site listed above. */
+int64_t alvq_conv1d_wgrad_workspace_bytes(int B, int C, int M, int L, int KW);
+int alvq_conv1d_wgrad_f32(const float* dy, const float* x, float* dw, float* dbias, void* workspace,
+                          int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vector quantiser (vq_vae/vector_quantizer.py:29-58).  x is the contiguous (B,D,L) buffer viewed as
+ * (N,D) rows in memory order (no permute, :32); codebook is (K,D).
+ * ---------------------------------------------------------------------------------------------- */
+/* idx[n] = argmin_k fl(fl(|x_n|^2 + |e_k|^2) - 2 x_n.e_k), lowest k on ties (:34-38).
+ * min_dist may be NULL.  workspace: alvq_vq_argmin_workspace_bytes(N,K) bytes. */
+int64_t alvq_vq_argmin_workspace_bytes(int64_t N, int K, int D);
+int alvq_vq_argmin_f32(const float* x, const float* codebook, int64_t* idx, float* min_dist, void* workspace,
+                       int64_t N, int K, int D, void* stream);
+
+/* q_st = x + (E[idx] - x) (:43,54);  sq_partials[ALVQ_VQ_PARTIALS] = per-workgroup partial sums of
+ * (E[idx]-x)^2 (fixed order, reproducible);  hist[k] += #rows with idx==k (int32[K], caller zeroes; may be NULL). */
+#define ALVQ_VQ_PARTIALS 1024
+int alvq_vq_gather_loss_f32(const float* x, const float* codebook, const int64_t* idx, float* q_st,
+                            float* sq_partials, int32_t* hist, int64_t N, int K, int D, void* stream);
+
+/* m = sum(sq_partials)/(N*D); loss = m + beta*m (:46-52); perplexity = exp(-sum p log(p+1e-10)), p = hist/N (:55-56).
+ * out[0] = loss, out[1] = perplexity. */
+int alvq_vq_finalize_f32(const float* sq_partials, const int32_t* hist, float* out, int64_t N, int K, int D,
+                         float beta, void* stream);
+
+/* Backward:  dx = g + gl*(2*beta/(N*D))*(x - E[idx]);
+ * dE[k] += gl*(2/(N*D)) * sum_{n: idx_n = k} (E[k] - x_n)  (skipped when dE == NULL, i.e. _train_vq False);
+ * g = grad wrt q_st (may be NULL = 0), gl = *grad_loss (device scalar, may be NULL = 1). dE must be zeroed by
+ * the caller (it is accumulated with float atomics). */
+int alvq_vq_backward_f32(const float* g, const float* grad_loss, const float* x, const float* codebook,
+                         const int64_t* idx, float* dx, float* dE, int64_t N, int K, int D, float beta, void* stream);
+
+/* Dense one-hot encodings (N,K) fp32 (:39-40) -- only materialised for get_latent_representation callers. */
+int alvq_onehot_f32(const int64_t* idx, float* encodings, int64_t N, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Jitter (vq_vae/modules/jitter.py:42-70): y[b,c,l] = x[b,c,src[l]];  backward: dx[b,c,l] = src[l]==l ? dy : 0.
+ * src is an int32[L] DEVICE array produced on the host with the reference's numpy call order.
+ * ---------------------------------------------------------------------------------------------- */
+int alvq_jitter_gather_f32(const float* x, const int32_t* src, float* y, int64_t rows, int L, int backward, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Callers' per-step arithmetic (scripts/train_speech.py:63-64,74; train_rir.py:42-49).
+ * ---------------------------------------------------------------------------------------------- */
+/* y[b,c,l] = (x' - mean_c x') / (std_c x' + 1e-8), x' = |x| if take_abs else x; unbiased std over dim=1;
+ * x, y are (B,C,L). */
+int alvq_standardise_f32(const float* x, float* y, int B, int C, int L, int take_abs, void* stream);
+
+/* loss[0] = mean((a-b)^2) over n elements (F.mse_loss, train_speech.py:74); workspace: ALVQ_EW_PARTIALS floats. */
+#define ALVQ_EW_PARTIALS 1024
+int alvq_mse_f32(const float* a, const float* b, float* loss, void* workspace, int64_t n, void* stream);
+/* grad = grad_loss[0] * (2/n) * (a - b)   (grad_loss: device scalar, NULL = 1). */
+int alvq_mse_backward_f32(const float* a, const float* b, const float* grad_loss, float* grad, int64_t n, void* stream);
+
+/* out = a + b (elementwise), used where a gradient has two consumers. */
+int alvq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* (B,R,C) -> (B,C,R) dense transpose (materialises permute(0,2,1), train_rir.py:45). */
+int alvq_transpose_f32(const float* x, float* y, int B, int R, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adam on a flat parameter buffer (torch.optim.Adam(lr, betas, eps, amsgrad=False), train_speech.py:154).
+ * step is 1-based. grad_scale multiplies the gradient first (1/world after the all-reduce).
+ * ---------------------------------------------------------------------------------------------- */
+int alvq_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * STFT power spectrogram (scripts/genereate_dataset.py:90-91,37,39,47-49; torchaudio Spectrogram semantics:
+ * center=True reflect pad, periodic Hann(n_fft), one-sided, window-normalised, |.|^2).
+ * wave (B,S) -> power (B, n_fft/2+1, 1+S/hop).
+ * ---------------------------------------------------------------------------------------------- */
+int alvq_stft_power_f32(const float* wave, float* power, int B, int S, int n_fft, int hop, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALVQ_H */
