@@ -92,6 +92,11 @@ __global__ __launch_bounds__(256) void mse_backward_kernel(const float* a, const
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) grad[e] = g * (a[e] - b[e]);
 }
 
+// out = t > 0 ? dy : 0   (ReLU backward with the saved post-ReLU activation; with dy == t it is ReLU itself)
+__global__ __launch_bounds__(256) void relu_mask_kernel(const float* dy, const float* t, float* out, long n) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) out[e] = t[e] > 0.f ? dy[e] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* out, long n) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) out[e] = a[e] + b[e];
 }
@@ -185,6 +190,13 @@ extern "C" int alvq_add_f32(const float* a, const float* b, float* out, int64_t 
   ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_add_f32: n <= 0");
   hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n);
   return check_launch("alvq_add_f32");
+}
+
+extern "C" int alvq_relu_mask_f32(const float* dy, const float* t, float* out, int64_t n, void* stream) {
+  ALVQ_REQUIRE(dy && t && out, ALVQ_EINVAL, "alvq_relu_mask_f32: null pointer");
+  ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_relu_mask_f32: n <= 0");
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, t, out, (long)n);
+  return check_launch("alvq_relu_mask_f32");
 }
 
 extern "C" int alvq_transpose_f32(const float* x, float* y, int B, int R, int C, void* stream) {

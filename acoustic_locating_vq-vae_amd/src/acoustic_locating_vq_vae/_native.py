@@ -43,6 +43,7 @@ _SIGNATURES = {
     "alvq_mse_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p]),
     "alvq_mse_backward_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p]),
     "alvq_add_f32": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
+    "alvq_relu_mask_f32": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
     "alvq_transpose_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_adam_f32": (_i32, [_c_void_p] * 4 + [_i64, _i32, _f32, _f32, _f32, _f32, _f32, _c_void_p]),
     "alvq_stft_power_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
@@ -98,6 +99,52 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual launches (bench.py's live roofline measurement).
+
+    Events are recorded on the stream the kernels are launched on (torch's current stream).  Usage:
+    ``with KernelTimer() as kt: ...``; then ``kt.summary()`` -> {family: (launches, seconds, flops)}.
+    """
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for family, flops, e0, e1 in self.records:
+            n, t, f = out.get(family, (0, 0.0, 0.0))
+            out[family] = (n + 1, t + e0.elapsed_time(e1) * 1e-3, f + flops)
+        return out
+
+
+class _timed:
+    __slots__ = ("family", "flops", "e0")
+
+    def __init__(self, family, flops):
+        self.family, self.flops = family, flops
+
+    def __enter__(self):
+        if KernelTimer.active is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        kt = KernelTimer.active
+        if kt is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            kt.records.append((self.family, self.flops, self.e0, e1))
+
+
 # ----------------------------------------------------------------------------------------------- conv
 def conv1d(x, w, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, w_layout=W_OIK,
            want_y2=False):
@@ -117,9 +164,10 @@ def conv1d(x, w, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=F
             raise RuntimeError("conv1d: %s has shape %s, expected %s" % (nm, tuple(t.shape), (B, M, L)))
     if bias is not None and bias.numel() != M:
         raise RuntimeError("conv1d: bias has %d elements, expected %d" % (bias.numel(), M))
-    rc = lib().alvq_conv1d_f32(_ptr(x, name="x"), _ptr(w, name="w"), _ptr(bias, name="bias"), _ptr(skip1, name="skip1"),
-                               _ptr(skip2, name="skip2"), _ptr(mask, name="mask"), _ptr(post, name="post"),
-                               _ptr(y), _ptr(y2), B, C, M, L, KW, w_layout, int(bool(relu)), _stream())
+    with _timed("conv1d_f32_kernel", 2.0 * B * L * M * C * KW):
+        rc = lib().alvq_conv1d_f32(_ptr(x, name="x"), _ptr(w, name="w"), _ptr(bias, name="bias"), _ptr(skip1, name="skip1"),
+                                   _ptr(skip2, name="skip2"), _ptr(mask, name="mask"), _ptr(post, name="post"),
+                                   _ptr(y), _ptr(y2), B, C, M, L, KW, w_layout, int(bool(relu)), _stream())
     _check(rc, "alvq_conv1d_f32")
     return (y, y2) if post is not None else y
 
@@ -155,9 +203,10 @@ def conv1d_wgrad(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, dbias_
     if nbytes < 0:
         raise RuntimeError("conv1d_wgrad: unsupported shape")
     ws = _workspace(nbytes, x.device)
-    rc = lib().alvq_conv1d_wgrad_f32(_ptr(dy, name="dy"), _ptr(x, name="x"), _ptr(dw_out, name="dw"),
-                                     _ptr(dbias_out, name="dbias") if want_bias else None, ws.data_ptr(),
-                                     B, C, M, L, KW, w_layout, int(bool(accumulate)), _stream())
+    with _timed("conv1d_wgrad_f32_kernel", 2.0 * B * L * M * C * KW):
+        rc = lib().alvq_conv1d_wgrad_f32(_ptr(dy, name="dy"), _ptr(x, name="x"), _ptr(dw_out, name="dw"),
+                                         _ptr(dbias_out, name="dbias") if want_bias else None, ws.data_ptr(),
+                                         B, C, M, L, KW, w_layout, int(bool(accumulate)), _stream())
     _check(rc, "alvq_conv1d_wgrad_f32")
     return (dw_out, dbias_out) if want_bias else dw_out
 
@@ -171,8 +220,9 @@ def vq_argmin(flat, codebook, want_dist=False):
     idx = torch.empty((N,), device=flat.device, dtype=torch.int64)
     dist = torch.empty((N,), device=flat.device, dtype=torch.float32) if want_dist else None
     ws = _workspace(lib().alvq_vq_argmin_workspace_bytes(N, K, D), flat.device)
-    rc = lib().alvq_vq_argmin_f32(_ptr(flat, name="x"), _ptr(codebook, name="codebook"), idx.data_ptr(),
-                                  _ptr(dist), ws.data_ptr(), N, K, D, _stream())
+    with _timed("vq_argmin_f32_kernel", 2.0 * N * K * D):
+        rc = lib().alvq_vq_argmin_f32(_ptr(flat, name="x"), _ptr(codebook, name="codebook"), idx.data_ptr(),
+                                      _ptr(dist), ws.data_ptr(), N, K, D, _stream())
     _check(rc, "alvq_vq_argmin_f32")
     return (idx, dist) if want_dist else idx
 
@@ -249,6 +299,13 @@ def mse_backward(a, b, grad_loss):
 def add(a, b):
     out = torch.empty_like(a)
     _check(lib().alvq_add_f32(_ptr(a, name="a"), _ptr(b, name="b"), _ptr(out), a.numel(), _stream()), "alvq_add_f32")
+    return out
+
+
+def relu_mask(dy, t):
+    """t > 0 ? dy : 0."""
+    out = torch.empty_like(dy)
+    _check(lib().alvq_relu_mask_f32(_ptr(dy, name="dy"), _ptr(t, name="t"), _ptr(out), dy.numel(), _stream()), "alvq_relu_mask_f32")
     return out
 
 

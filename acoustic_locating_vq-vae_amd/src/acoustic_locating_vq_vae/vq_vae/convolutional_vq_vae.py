@@ -1,0 +1,80 @@
+"""``ConvolutionalVQVAE`` -- encoder -> pre-VQ conv -> vector quantiser -> decoder.
+
+Reference: vq_vae/convolutional_vq_vae.py:18-105.  Same constructor, attributes, state_dict keys and
+return values; every tensor op runs as a hand-written gfx950 kernel through libalvq.so.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import optim
+from torch.utils.data import DataLoader
+
+from acoustic_locating_vq_vae.vq_vae.convolutional_encoder import ConvolutionalEncoder
+from acoustic_locating_vq_vae.vq_vae.deconvolutional_decoder import DeconvolutionalDecoder
+from acoustic_locating_vq_vae.vq_vae.vector_quantizer import VectorQuantizer
+
+from . import _init
+from .. import _native, _ops
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class ConvolutionalVQVAE(nn.Module):
+    def __init__(self, in_channels: int, num_hiddens: int, embedding_dim: int, num_residual_layers: int,
+                 num_residual_hiddens: int, commitment_cost: float, num_embeddings: int, use_jitter: bool = True,
+                 encoder_average_pooling: bool = False, out_channels: int = None):
+        out_channels = in_channels if out_channels is None else out_channels
+        super().__init__()
+        self.encoder_average_pooling = encoder_average_pooling
+        self._encoder = ConvolutionalEncoder(in_channels, num_hiddens, num_residual_layers, num_residual_hiddens)
+        self._pre_vq_conv = _init.kaiming_conv(nn.Conv1d(num_hiddens, embedding_dim, kernel_size=3, padding=1))
+        self._vq = VectorQuantizer(num_embeddings, embedding_dim, commitment_cost)
+        self._decoder = DeconvolutionalDecoder(embedding_dim, out_channels, num_hiddens, num_residual_layers,
+                                               num_residual_hiddens, use_jitter, 0.25)
+
+    def get_embedding_dim(self):
+        return self._vq.get_embedding_dim()
+
+    def _latent(self, x):
+        z = self._encoder(x)
+        z = _ops.ConvFn.apply(z, self._pre_vq_conv.weight, self._pre_vq_conv.bias, _ops.OIK)
+        return z
+
+    def forward(self, x):
+        z = self._latent(x)
+        if self.encoder_average_pooling:
+            z = torch.mean(z, dim=2, keepdim=True)
+        loss, quantized, perplexity, _ = self._vq.quantize(z)
+        x_recon = self._decoder(quantized)
+        return loss, x_recon, perplexity
+
+    def get_latent_representation(self, x):
+        return self._vq(self._latent(x))
+
+    def get_latent_indices(self, x):
+        """(loss, quantized, perplexity, indices[N] int64): the sparse form of get_latent_representation."""
+        return self._vq.quantize(self._latent(x))
+
+    def train_on_data(self, optimizer: optim, dataloader: DataLoader, num_training_updates, data_variance):
+        """The alternative loop the reference keeps on the class (convolutional_vq_vae.py:58-91)."""
+        self.train()
+        recon_log, perp_log = [], []
+        for i in range(num_training_updates):
+            (inputs, _) = next(iter(dataloader))
+            inputs = inputs.to(device)
+            optimizer.zero_grad()
+            vq_loss, data_recon, perplexity = self(inputs)
+            target = inputs if inputs.shape == data_recon.shape else inputs[:, :, :-1]
+            recon_error = F.mse_loss(data_recon, target) / data_variance
+            (recon_error + vq_loss).backward()
+            optimizer.step()
+            recon_log.append(recon_error.item())
+            perp_log.append(perplexity.item())
+            if (i + 1) % 100 == 0:
+                print('%d iterations' % (i + 1))
+                print('recon_error: %.3f' % np.mean(recon_log[-100:]))
+                print('perplexity: %.3f' % np.mean(perp_log[-100:]))
+                print()
+        self.train_res_recon_error = recon_log
+        self.train_res_perplexity = perp_log

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spectrograms/s of one full VQ-VAE train step (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = standardise -> encoder -> pre-VQ conv -> VQ -> decoder -> MSE -> backward -> [one RCCL all-reduce of
+the flat gradient buffer] -> Adam, on a synthetic (B,201,500) batch already resident in HBM (speech ctor of
+scripts/train_speech.py:152-153, B=64 per GPU, weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "acoustic_locating_vq-vae_amd")
+for _p in (ROOT, PKG, os.path.join(PKG, "src")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 matrix rate (= vector rate)
+SPEECH_CFG = (201, 1024, 128, 3, 1024, 0.25, 1024)          # scripts/train_speech.py:152-153
+RIR_CFG = (500, 1024, 64, 2, 64, 0.25, 1024)                # scripts/train_rir.py:147-149
+
+
+def algorithmic_gflop_per_spectrogram(cfg, L, out_channels=None):
+    """train = 3*F_conv - (no dgrad into the input) + VQ distance GEMM (forward only)."""
+    c, h, d, r, rh, _, k = cfg
+    oc = c if out_channels is None else out_channels
+    enc1 = 2 * c * h * 3 * L
+    res = 2 * h * rh * 3 * L + 2 * rh * h * L
+    pre = 2 * h * d * 3 * L
+    dec1 = 2 * d * h * 3 * L
+    up = 2 * h * h * 3 * L
+    last = 2 * h * oc * 3 * L
+    f_conv = enc1 + 2 * r * res + pre + dec1 + 2 * up + last
+    return (3 * f_conv - enc1 + 2 * L * k * d) / 1e9
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle restatement (kind "port") timed on this host: speech ctor, B=4 (BASELINE configs[0])."""
+    from oracle import vqvae_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    shapes = O.vqvae_param_shapes(201, 1024, 128, 1024, 1024)
+    params = O.closed_form_params(shapes, codebook_scale=1.0, gain=0.5)
+    tr = O.OracleTrainer(params, 3, 0.25, use_jitter=True)
+    x = O.speech_preprocess(torch.randn(4, 201, 500))
+    np.random.seed(0)
+    tr.step(x)                                   # warm-up
+    times, t_end = [], time.time() + seconds_budget
+    while len(times) < 3 or (time.time() < t_end and len(times) < 12):
+        t0 = time.time()
+        tr.step(x)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": 4.0 / med, "unit": "spectrograms/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps of the CPU oracle (same ATen op sequence as the reference), speech ctor, "
+                      "B=4 x (201,500) fp32, jitter on, Adam; median %.3f s/step" % (len(times), med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU")
+    ap.add_argument("--config", default="speech", choices=["speech", "rir"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from acoustic_locating_vq_vae import _native as N
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    from acoustic_locating_vq_vae.train_step import Trainer
+
+    torch.manual_seed(0)                         # identical init on every rank (also broadcast by Trainer)
+    np.random.seed(1234 + rank)                  # jitter: per-rank numpy stream
+    B = args.batch
+    if args.config == "speech":
+        cfg, L, oc = SPEECH_CFG, 500, None
+        model = ConvolutionalVQVAE(*cfg).cuda()
+        kind = "speech"
+    else:
+        cfg, L, oc = RIR_CFG, 201, 1
+        model = ConvolutionalVQVAE(*cfg, use_jitter=False, out_channels=1).cuda()
+        kind = "rir"
+    model.train()
+    trainer = Trainer(model, kind)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + rank)
+    raw = torch.randn(B, 201, 500, device="cuda", generator=g)      # synthetic spectrogram batch, resident in HBM
+    wiener = torch.randn(B, 201, device="cuda", generator=g) if kind == "rir" else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = trainer.step(raw, wiener)
+    barrier()
+    timer = None if args.no_kernel_timer else N.KernelTimer()
+    if timer is not None:
+        timer.__enter__()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(raw, wiener)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if timer is not None:
+        timer.__exit__()
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out[0])
+    assert np.isfinite(loss), "non-finite loss"
+
+    if rank == 0:
+        gf = algorithmic_gflop_per_spectrogram(cfg, L, oc)
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "spectrograms/sec (train step), speech VQ-VAE default config",
+            "value": value, "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s VQ-VAE train step (fwd+bwd+Adam), ctor %s, B=%d per GPU x (%s) fp32, jitter %s"
+                                   % (kind, list(cfg), B, "201,500" if kind == "speech" else "500,201",
+                                      "on" if kind == "speech" else "off"),
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "algorithmic_gflop_per_spectrogram": gf},
+            "model_tflops": value * gf / 1e3,
+            "final_loss": loss,
+        }
+        if timer is not None:
+            summ = timer.summary()
+            fam = "conv1d_f32_kernel"
+            if fam in summ:
+                n, secs, flops = summ[fam]
+                ach = flops / secs / 1e12
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "traffic.json")
+                if os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get(fam)
+                line["roofline"] = {"bound": "mfma", "kernel": fam, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                                    "launches": n, "avg_launch_ms": 1e3 * secs / n,
+                                    "algorithmic_gflop_per_launch": flops / n / 1e9}
+            line["kernel_families"] = {k: {"launches": v[0], "ms_per_step": 1e3 * v[1] / args.steps,
+                                           "tflops": (v[2] / v[1] / 1e12) if v[1] > 0 else None}
+                                       for k, v in summ.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

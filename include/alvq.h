@@ -128,6 +128,9 @@ int alvq_mse_backward_f32(const float* a, const float* b, const float* grad_loss
 /* out = a + b (elementwise), used where a gradient has two consumers. */
 int alvq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* out = t > 0 ? dy : 0: ReLU backward from the saved post-ReLU activation (F.relu, residual_stack.py:46). */
+int alvq_relu_mask_f32(const float* dy, const float* t, float* out, int64_t n, void* stream);
+
 /* (B,R,C) -> (B,C,R) dense transpose (materialises permute(0,2,1), train_rir.py:45). */
 int alvq_transpose_f32(const float* x, float* y, int B, int R, int C, void* stream);
 

@@ -77,7 +77,8 @@ def test_conv_dgrad_and_wgrad(B, C, M, L, KW):
     assert rel(dx, x.grad) < 2e-5
     dw, db = N.conv1d_wgrad(dev(dy), dev(x.detach()), KW, N.W_OIK, want_bias=True)
     assert rel(dw, w.grad) < 2e-5
-    assert rel(db, b.grad) < 2e-5
+    # a bias grad is a plain sum of B*L terms that cancel: judge it against the magnitude summed
+    assert float((db.cpu() - b.grad).abs().max()) < 2e-6 * float(dy.abs().sum(dim=(0, 2)).max())
     # accumulate (shared residual weights)
     dw2 = N.conv1d_wgrad(dev(dy), dev(x.detach()), KW, N.W_OIK, dw_out=dw.clone(), accumulate=True)
     assert rel(dw2, 2 * w.grad) < 2e-5

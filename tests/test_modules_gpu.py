@@ -1,0 +1,285 @@
+"""T3/T5: the module API on the HIP path against the CPU oracle and the goldens captured from the real
+reference.  Tolerance 1e-3 relative (north_star) on outputs/grads -- observed ~1e-5; indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vqvae_oracle as O  # noqa: E402
+
+TOL = 1e-3
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def sl(t, n=64):
+    f = t.detach().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].cpu().numpy()
+
+
+def expand(p, R):
+    out = {}
+    for k, v in p.items():
+        if "_layers.0." in k:
+            for r in range(R):
+                out[k.replace("_layers.0.", "_layers.%d." % r)] = v
+        else:
+            out[k] = v
+    return out
+
+
+def build(cfg, p=None, **kw):
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    m = ConvolutionalVQVAE(*cfg, **kw)
+    if p is not None:
+        m.load_state_dict(expand(p, cfg[3]))
+    return m.cuda()
+
+
+def oracle_params(m):
+    return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()
+            if "_layers." not in k or "_layers.0." in k}
+
+
+def test_g1_tiny_against_reference_golden(golden_dir):
+    from acoustic_locating_vq_vae.train_step import Trainer
+    g = np.load(os.path.join(golden_dir, "g1_tiny_vqvae.npz"))
+    p = {k[len("param:"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param:")}
+    m = build((7, 16, 4, 2, 8, 0.25, 16), p)
+    m.train()
+    tr = Trainer(m, "speech")
+    x_raw = torch.from_numpy(g["x_raw"]).cuda()
+    x, _ = tr.preprocess(x_raw)
+    assert rel(x, g["x"]) < 1e-5
+    z = m._latent(x)
+    assert rel(z, g["z"]) < 1e-5
+    _, q_st, _, enc = m.get_latent_representation(x)
+    assert np.array_equal(enc.argmax(1).cpu().numpy(), g["idx"])
+    assert np.array_equal(enc.cpu().numpy(), g["encodings"])
+    assert rel(q_st, g["q_st"]) < 1e-5
+    np.random.seed(5)
+    loss, recon_error, perp = tr.step(x_raw)
+    assert rel(recon_error, g["recon_error"]) < 1e-4
+    assert rel(loss, g["recon_error"] + g["vq_loss"]) < 1e-4
+    assert rel(perp, g["perplexity"]) < 1e-5
+    named = dict(m.named_parameters())
+    for k in p:
+        assert rel(named[k].grad, g["grad:" + k]) < TOL, k
+        assert rel(named[k].grad, g["grad:" + k]) < 1e-4, k
+        assert float((named[k].detach().cpu() - torch.from_numpy(g["after:" + k])).abs().max()) < 5e-6, k
+    # same seed -> same jitter columns -> same reconstruction
+    m2 = build((7, 16, 4, 2, 8, 0.25, 16), p).train()
+    np.random.seed(5)
+    _, recon, _ = m2(x)
+    assert rel(recon, g["recon"]) < 1e-4
+
+
+CASES = [
+    # cfg (in,H,D,R,RH,beta,K), input shape (B,C,L), kwargs, permuted
+    ((7, 16, 4, 2, 8, 0.25, 16), (2, 7, 13), dict(), False),
+    ((20, 48, 8, 3, 24, 0.25, 64), (3, 20, 40), dict(use_jitter=False), False),
+    ((33, 64, 16, 1, 64, 0.5, 32), (2, 33, 64), dict(), False),
+    ((50, 64, 8, 2, 16, 0.25, 64), (4, 24, 50), dict(use_jitter=False, out_channels=1), True),
+    ((201, 128, 32, 2, 128, 0.25, 128), (2, 201, 96), dict(), False),
+]
+
+
+@pytest.mark.parametrize("cfg,shape,kw,permuted", CASES)
+def test_forward_backward_matches_oracle(cfg, shape, kw, permuted):
+    torch.manual_seed(11)
+    m = build(cfg, **kw)
+    with torch.no_grad():
+        m._vq._embedding.weight.normal_(0, 0.7)      # data-scale codebook: wide argmin margins
+    m.train()
+    p = oracle_params(m)
+    x = O.standardise(torch.randn(*shape).abs())
+    if permuted:
+        x = x.permute(0, 2, 1)
+    oc = kw.get("out_channels")
+    target = x if oc is None else torch.randn(shape[0], oc, x.shape[2])
+    use_jitter = kw.get("use_jitter", True)
+    np.random.seed(3)
+    src = O.jitter_source_index(x.shape[2], 0.25) if use_jitter else None
+    out = O.vqvae_forward(x, p, cfg[3], cfg[5], src)
+    (F.mse_loss(out["recon"], target) + out["vq_loss"]).backward()
+
+    xg = x.cuda().requires_grad_(True)
+    np.random.seed(3)
+    vq_loss, recon, perp = m(xg)
+    (F.mse_loss(recon, target.cuda()) + vq_loss).backward()
+    _, _, _, idx = m.eval().get_latent_indices(x.cuda())
+    assert torch.equal(idx.cpu(), out["idx"])
+    assert rel(recon, out["recon"]) < 1e-4
+    assert rel(vq_loss, out["vq_loss"]) < 1e-5 and rel(perp, out["perplexity"]) < 1e-5
+    named = dict(m.named_parameters())
+    for k, v in p.items():
+        assert rel(named[k].grad, v.grad) < 1e-4, k
+    assert xg.grad is not None and xg.grad.shape == x.shape
+
+
+def test_eval_mode_has_no_jitter_and_is_deterministic():
+    torch.manual_seed(1)
+    m = build((7, 16, 4, 2, 8, 0.25, 16)).eval()
+    x = torch.randn(2, 7, 13).cuda()
+    a = m(x)[1]
+    b = m(x)[1]
+    assert torch.equal(a, b)
+    p = oracle_params(m)
+    out = O.vqvae_forward(x.cpu(), p, 2, 0.25, None)
+    assert rel(a, out["recon"]) < 1e-4
+
+
+def test_average_pooling_path_shapes():
+    m = build((7, 16, 4, 2, 8, 0.25, 16), encoder_average_pooling=True, out_channels=3).eval()
+    loss, recon, perp = m(torch.randn(5, 7, 13).cuda())
+    assert recon.shape == (5, 3, 1)
+    out = O.vqvae_forward(torch.randn(5, 7, 13), oracle_params(m), 2, 0.25, None, average_pooling=True)
+    assert out["recon"].shape == (5, 3, 1)
+
+
+def test_submodules_standalone():
+    from acoustic_locating_vq_vae.vq_vae.modules.residual_stack import ResidualStack
+    from acoustic_locating_vq_vae.vq_vae.modules.residual import Residual
+    from acoustic_locating_vq_vae.vq_vae.modules.jitter import Jitter
+    from acoustic_locating_vq_vae.vq_vae.vector_quantizer import VectorQuantizer
+    torch.manual_seed(2)
+    st = ResidualStack(12, 12, 3, 6).cuda()
+    h = torch.randn(2, 12, 9)
+    w1, w2 = (w.detach().cpu().requires_grad_(True) for w in st.weights)
+    hc = h.clone().requires_grad_(True)
+    ref = O.residual_stack(hc, w1, w2, 3)
+    ref.sum().backward()
+    hg = h.cuda().requires_grad_(True)
+    got = st(hg)
+    got.sum().backward()
+    assert rel(got, ref) < 1e-5 and rel(hg.grad, hc.grad) < 1e-5
+    assert rel(st.weights[0].grad, w1.grad) < 1e-5 and rel(st.weights[1].grad, w2.grad) < 1e-5
+    res = Residual(12, 12, 6).cuda()
+    r1, r2 = (w.detach().cpu() for w in res.weights)
+    t = F.relu(h)
+    want = t + F.conv1d(F.relu(F.conv1d(t, r1, padding=1)), r2)
+    assert rel(res(h.cuda()), want) < 1e-5
+    np.random.seed(4)
+    q = torch.randn(2, 3, 17).cuda().requires_grad_(True)
+    y = Jitter(0.25)(q)
+    np.random.seed(4)
+    src = O.jitter_source_index(17, 0.25)
+    assert torch.equal(y.detach().cpu(), q.detach().cpu()[:, :, torch.from_numpy(src)])
+    y.sum().backward()
+    assert torch.equal(q.grad.cpu()[0, 0], torch.from_numpy((src == np.arange(17)).astype(np.float32)))
+    vq = VectorQuantizer(16, 4, 0.25).cuda()
+    vq.set_train_vq(False)
+    z = torch.randn(2, 4, 6).cuda().requires_grad_(True)
+    loss, q2, perp, enc = vq(z)
+    (loss + q2.sum()).backward()
+    assert vq._embedding.weight.grad is None or float(vq._embedding.weight.grad.abs().max()) == 0.0
+    assert enc.shape == (12, 16) and float(enc.sum()) == 12.0
+
+
+def _default(tag):
+    if tag == "speech":
+        return (201, 1024, 128, 3, 1024, 0.25, 1024), (2, 201, 500), False, None, True
+    return (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False
+
+
+@pytest.mark.parametrize("tag", ["speech", "rir"])
+def test_g3_default_configs_against_reference_golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "g3_%s.npz" % tag))
+    cfg, shape, permuted, oc, jit = _default(tag)
+    in_c, h, d, r, rh, beta, k = cfg
+    p = O.closed_form_params(O.vqvae_param_shapes(in_c, h, d, rh, k, oc), float(g["cb_scale"]), float(g["gain"]))
+    m = build(cfg, p, use_jitter=jit, out_channels=oc).train()
+    x = O.speech_preprocess(torch.from_numpy(O.hashed_uniform(int(np.prod(shape)), 21, 2.0).reshape(shape)))
+    if permuted:
+        x = x.permute(0, 2, 1)
+    if oc is None:
+        target = x
+    else:
+        tr = torch.from_numpy(O.hashed_uniform(shape[0] * x.shape[2], 22, 2.0).reshape(shape[0], x.shape[2]))
+        target = O.standardise(tr).unsqueeze(1)
+    xg = x.cuda()                                   # RIR: a permuted (non-contiguous) view, as train_rir.py:45 hands over
+    z = m._latent(xg)
+    assert rel(sl(z), g["z_slice"]) < 1e-4
+    _, _, _, idx = m.get_latent_indices(xg)
+    idx = idx.cpu().numpy().astype(np.int16)
+    bad = np.nonzero(idx != g["idx"])[0]
+    gap = (g["top2_val"][:, 1] - g["top2_val"][:, 0]) / np.abs(g["top2_val"][:, 0])
+    assert all(gap[i] < 1e-5 for i in bad), (bad, gap[bad])      # bit-exact except on reference near-ties
+    assert len(bad) == 0
+    np.random.seed(9)
+    vq_loss, recon, perp = m(xg)
+    err = F.mse_loss(recon, target.cuda())
+    (err + vq_loss).backward()
+    assert rel(vq_loss, g["vq_loss"]) < 1e-4 and rel(err, g["recon_error"]) < 1e-4
+    assert rel(perp, g["perplexity"]) < 1e-5
+    assert rel(sl(recon), g["recon_slice"]) < TOL
+    for key, pp in m.named_parameters():
+        assert rel(sl(pp.grad), g["grad_slice:" + key]) < TOL, key
+        f = pp.grad.detach().double().flatten()
+        assert abs(float((f * f).sum()) - g["grad_sum:" + key][2]) <= 1e-3 * g["grad_sum:" + key][2] + 1e-20, key
+
+
+def test_echoed_model_against_oracle_and_golden(golden_dir):
+    from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
+    from acoustic_locating_vq_vae.train_step import Trainer
+    g = np.load(os.path.join(golden_dir, "g3_echoed.npz"))
+    gain = float(g["gain"])
+    sp_p = O.closed_form_params(O.vqvae_param_shapes(201, 1024, 128, 1024, 1024), float(g["speech_cb_scale"]), gain)
+    rir_p = O.closed_form_params(O.vqvae_param_shapes(500, 1024, 64, 64, 1024, 1), float(g["rir_cb_scale"]), gain)
+    sp = build((201, 1024, 128, 3, 1024, 0.25, 1024), sp_p)
+    rir = build((500, 1024, 64, 2, 64, 0.25, 1024), rir_p, use_jitter=False, out_channels=1)
+    model = EchoedSpeechReconModel(rir, sp, 201, 1024, 2, 1024, True)
+    dec_p = O.closed_form_params(O.decoder_param_shapes(192, 201, 1024, 1024), gain=gain)
+    model._decoder.load_state_dict({k[len("_decoder."):]: v for k, v in expand(dec_p, 2).items()})
+    model = model.cuda().train()
+    shape = (2, 201, 500)
+    raw = torch.from_numpy(O.hashed_uniform(int(np.prod(shape)), 21, 2.0).reshape(shape)).abs()
+    tr = Trainer(model, "echoed")
+    np.random.seed(9)
+    loss, err, sperp = tr.step(raw.cuda())
+    assert rel(err, g["recon_error"]) < 1e-4
+    assert rel(sperp, g["speech_perplexity"]) < 1e-5
+    for key, pp in model._decoder.named_parameters():
+        assert rel(sl(pp.grad), g["grad_slice:_decoder." + key]) < TOL, key
+    assert all(p.grad is None for p in model.speech_model.parameters())
+    # fine-tuning mode lets gradients into both encoders (encoder_training_echoed_model.py:43-46)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    model.set_train_encoder(True)
+    x = O.standardise(raw).cuda()
+    recon, _, _ = model(x, x.permute(0, 2, 1))
+    recon.square().mean().backward()
+    assert model.speech_model._encoder._conv_1.weight.grad is not None
+    assert model.rir_model._pre_vq_conv.weight.grad.abs().sum() > 0
+    assert model.speech_model._vq._embedding.weight.grad is None or float(model.speech_model._vq._embedding.weight.grad.abs().max()) == 0
+
+
+def test_train_steps_track_oracle_trainer():
+    """T5: K steps from identical init/inputs: loss curve vs the CPU oracle trainer."""
+    from acoustic_locating_vq_vae.train_step import Trainer
+    torch.manual_seed(5)
+    cfg = (20, 48, 8, 2, 24, 0.25, 64)
+    m = build(cfg)
+    with torch.no_grad():
+        m._vq._embedding.weight.normal_(0, 0.7)
+    m.train()
+    ot = O.OracleTrainer(oracle_params(m), 2, 0.25, use_jitter=True)
+    tr = Trainer(m, "speech")
+    raw = torch.randn(4, 20, 40)
+    x = O.speech_preprocess(raw)
+    for step in range(4):
+        np.random.seed(100 + step)
+        want = ot.step(x)
+        np.random.seed(100 + step)
+        got = tr.step(raw.cuda())
+        assert abs(float(got[0]) - want[0]) < 2e-3 * abs(want[0]), (step, float(got[0]), want[0])
+        assert abs(float(got[2]) - want[2]) < 1e-2 * abs(want[2]) + 1e-3
