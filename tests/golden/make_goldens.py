@@ -66,6 +66,8 @@ def g1_tiny():
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=False)
     opt.zero_grad()
     z = model._pre_vq_conv(model._encoder(x))
+    with torch.no_grad():
+        _, q_st, _, enc = model.get_latent_representation(x)      # before the optimiser step
     np.random.seed(5)
     vq_loss, recon, perp = model(x)
     recon_error = F.mse_loss(recon, x)
@@ -75,8 +77,6 @@ def g1_tiny():
     after = {k: pp.detach().clone() for k, pp in model.named_parameters()}
     np.random.seed(5)
     src = O.jitter_source_index(13, 0.25)
-    with torch.no_grad():
-        _, q_st, _, enc = model.eval().get_latent_representation(x)
     out = {"x_raw": x_raw.numpy(), "x": x.numpy(), "z": z.detach().numpy(), "idx": enc.argmax(1).numpy().astype(np.int64),
            "q_st": q_st.numpy(), "vq_loss": vq_loss.detach().numpy(), "recon_error": recon_error.detach().numpy(),
            "perplexity": perp.detach().numpy(), "recon": recon.detach().numpy(), "jitter_src": src,
