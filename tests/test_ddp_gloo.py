@@ -1,0 +1,119 @@
+"""T4 (CPU variant): the data-parallel plumbing with world_size 2 over gloo.
+
+The HIP kernels cannot run here, so the model math is the CPU oracle; what is under test is the product's
+FlatBuffers / shard_batch / sync_grads logic: N-rank grads after the ONE all-reduce (scaled by 1/world) equal
+1-rank grads on the concatenated batch, and every rank ends a step with identical parameters."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _setup_paths():
+    pkg = os.path.join(ROOT, "acoustic_locating_vq-vae_amd")
+    for p in (ROOT, pkg, os.path.join(pkg, "src")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _loss(p, x, O):
+    out = O.vqvae_forward(x, p, 2, 0.25, None)
+    return F.mse_loss(out["recon"], x) + out["vq_loss"]
+
+
+def _worker(rank, world, port, ret):
+    _setup_paths()
+    from oracle import vqvae_oracle as O
+    from acoustic_locating_vq_vae.train_step import FlatBuffers, shard_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    calls = {"n": 0}
+    real_all_reduce = dist.all_reduce
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real_all_reduce(*a, **k)
+
+    dist.all_reduce = counting
+    shapes = O.vqvae_param_shapes(7, 16, 4, 8, 16)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.closed_form_params(shapes, 0.8).items()}
+    if rank == 1:                                   # deliberately different init: broadcast must fix it
+        with torch.no_grad():
+            for v in p.values():
+                v.add_(1.0)
+    fb = FlatBuffers(p.values())
+    fb.broadcast_params()
+    xg = O.speech_preprocess(torch.from_numpy(O.hashed_uniform(4 * 7 * 13, 3, 2.0).reshape(4, 7, 13)))
+    x = shard_batch(xg, rank, world)
+    fb.zero_grad()
+    _loss(p, x, O).backward()
+    scale = fb.sync_grads()
+    assert calls["n"] == 1, "exactly one collective per step"
+    assert abs(scale - 1.0 / world) < 1e-12
+    grads = (fb.grad * scale).clone()
+    with torch.no_grad():
+        fb.flat.add_(grads, alpha=-0.1)             # any deterministic optimiser: ranks must stay identical
+    gathered = [torch.zeros_like(fb.flat) for _ in range(world)]
+    dist.all_gather(gathered, fb.flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    if rank == 0:
+        ret["grads"] = grads.numpy()
+        ret["same"] = same
+        ret["views_alive"] = all(q.grad.data_ptr() == fb.grad.data_ptr() + 4 * o for q, o in zip(fb.params, fb.offsets))
+    dist.destroy_process_group()
+
+
+def test_two_rank_grads_equal_single_rank_on_full_batch():
+    _setup_paths()
+    from oracle import vqvae_oracle as O
+    from acoustic_locating_vq_vae.train_step import FlatBuffers
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret["same"] and ret["views_alive"]
+    shapes = O.vqvae_param_shapes(7, 16, 4, 8, 16)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.closed_form_params(shapes, 0.8).items()}
+    fb = FlatBuffers(p.values())
+    xg = O.speech_preprocess(torch.from_numpy(O.hashed_uniform(4 * 7 * 13, 3, 2.0).reshape(4, 7, 13)))
+    fb.zero_grad()
+    _loss(p, xg, O).backward()
+    ref = fb.grad.numpy()
+    err = np.abs(ret["grads"] - ref).max() / (np.abs(ref).max() + 1e-30)
+    assert err < 1e-5, err
+
+
+def test_flat_buffers_views_and_shard():
+    _setup_paths()
+    from acoustic_locating_vq_vae.train_step import FlatBuffers, shard_batch, unique_trainable
+    a = torch.nn.Parameter(torch.randn(5, 3))
+    b = torch.nn.Parameter(torch.randn(7))
+    frozen = torch.nn.Parameter(torch.randn(2), requires_grad=False)
+    fb = FlatBuffers([a, b, a, frozen])
+    assert len(fb.params) == 2 and fb.numel == 22 and fb.flat.numel() == 128
+    assert a.data_ptr() == fb.flat.data_ptr() and b.data_ptr() == fb.flat.data_ptr() + 64 * 4
+    (a.sum() * 2 + b.sum()).backward()
+    assert float(fb.grad[:15].sum()) == 30.0 and float(fb.grad[64:71].sum()) == 7.0
+    fb.zero_grad()
+    assert float(fb.grad.abs().sum()) == 0.0 and a.grad.data_ptr() == fb.grad.data_ptr()
+    x = torch.arange(8).view(8, 1)
+    assert shard_batch(x, 1, 4).view(-1).tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        shard_batch(x, 0, 3)
+    assert fb.sync_grads() == 1.0                    # no process group: identity
