@@ -8,6 +8,7 @@
 // The input tile (BK channels x BN+2 positions) is staged ONCE in LDS per K-chunk and reused by all three
 // taps -- that is the "im2col-free" part; HBM reads are coalesced along L.
 #include "alvq_common.h"
+#include "wgrad_reduce.h"
 
 namespace alvq {
 
@@ -337,31 +338,6 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_f32_kernel(WgradArgs a) {
           const int c = c0 + wc0 + ni * 16 + li;
           if (m < M && c < C) out[((long)t * M + m) * C + c] = acc[t][mi][ni][r];
         }
-}
-
-// dw (+)= sum_s partial[s]; fixed summation order -> bitwise reproducible.
-// OIK: dw[m][c][t].   IOK: dw[c][m][KW-1-t].
-__global__ void wgrad_reduce_kernel(const float* partial, float* dw, int splits, int KW, int M, int C, int w_layout,
-                                    int accumulate) {
-  const long total = (long)KW * M * C;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    // e indexes the OUTPUT (coalesced writes); decode to (m, c, t)
-    int m, c, t;
-    if (w_layout == ALVQ_W_OIK) {
-      t = (int)(e % KW);
-      c = (int)((e / KW) % C);
-      m = (int)(e / ((long)KW * C));
-    } else {
-      const int tt = (int)(e % KW);
-      t = KW - 1 - tt;
-      m = (int)((e / KW) % M);
-      c = (int)(e / ((long)KW * M));
-    }
-    const long src = ((long)t * M + m) * C + c;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partial[(long)k * total + src];
-    dw[e] = accumulate ? dw[e] + s : s;
-  }
 }
 
 // dbias[m] (+)= sum_b sum_l dy[b,m,l]; one workgroup per channel, fixed order.

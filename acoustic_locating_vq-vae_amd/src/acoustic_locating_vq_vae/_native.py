@@ -47,6 +47,16 @@ _SIGNATURES = {
     "alvq_transpose_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_adam_f32": (_i32, [_c_void_p] * 4 + [_i64, _i32, _f32, _f32, _f32, _f32, _f32, _c_void_p]),
     "alvq_stft_power_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_nlc_rows": (_i64, [_i32, _i32]),
+    "alvq_nlc_channels": (_i32, [_i32]),
+    "alvq_nlc_guard_rows": (_i32, []),
+    "alvq_packed_weight_elems": (_i64, [_i32, _i32, _i32]),
+    "alvq_pack_weight_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_ncl_to_nlc_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
+    "alvq_relu_mask_bf16": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
+    "alvq_conv1d_bf16": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p]),
+    "alvq_conv1d_wgrad_bf16_workspace_bytes": (_i64, [_i32] * 5),
+    "alvq_conv1d_wgrad_bf16": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -328,3 +338,124 @@ def stft_power(wave, n_fft=400, hop=160):
     power = torch.empty((B, n_fft // 2 + 1, 1 + S // hop), device=wave.device, dtype=torch.float32)
     _check(lib().alvq_stft_power_f32(_ptr(wave, name="wave"), _ptr(power), B, S, n_fft, hop, _stream()), "alvq_stft_power_f32")
     return power
+
+
+# ----------------------------------------------------------------------------------------------- bf16 path
+class NLC:
+    """A bf16 activation in the NLC-padded layout (see include/alvq.h): storage = guard rows + matrix + guard rows."""
+    __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard")
+
+    def __init__(self, B, L, C, device):
+        L_ = lib()
+        self.B, self.L, self.C = B, L, C
+        self.Cp = L_.alvq_nlc_channels(C)
+        self.rows = L_.alvq_nlc_rows(B, L)
+        self.guard = L_.alvq_nlc_guard_rows()
+        self.storage = torch.empty(((self.rows + 2 * self.guard) * self.Cp,), device=device, dtype=torch.bfloat16)
+
+    @classmethod
+    def wrap(cls, storage, B, L, C):
+        self = cls.__new__(cls)
+        L_ = lib()
+        self.B, self.L, self.C = B, L, C
+        self.Cp, self.rows, self.guard = L_.alvq_nlc_channels(C), L_.alvq_nlc_rows(B, L), L_.alvq_nlc_guard_rows()
+        self.storage = storage
+        return self
+
+    @property
+    def ptr(self):
+        return self.storage.data_ptr() + self.guard * self.Cp * 2
+
+    def matrix(self):
+        g = self.guard * self.Cp
+        return self.storage[g:g + self.rows * self.Cp].view(self.rows, self.Cp)
+
+    def to_ncl(self):
+        """(B,C,L) fp32 copy -- test/debug helper (torch indexing, not on the hot path)."""
+        m = self.matrix()[1:1 + self.B * (self.L + 1)].view(self.B, self.L + 1, self.Cp)
+        return m[:, :self.L, :self.C].permute(0, 2, 1).float().contiguous()
+
+
+def nlc_like(ref, C):
+    return NLC(ref.B, ref.L, C, ref.storage.device)
+
+
+def _nlc_ptr(t, ref, C, name):
+    if t is None:
+        return None
+    if not isinstance(t, NLC) or (t.B, t.L, t.C) != (ref.B, ref.L, C):
+        raise RuntimeError("%s: expected an NLC activation of (B=%d, L=%d, C=%d)" % (name, ref.B, ref.L, C))
+    return t.ptr
+
+
+def ncl_to_nlc(x):
+    """(B,C,L) fp32 dense -> NLC bf16."""
+    B, C, L = x.shape
+    out = NLC(B, L, C, x.device)
+    _check(lib().alvq_ncl_to_nlc_bf16(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16")
+    return out
+
+
+def pack_weight(w, w_layout):
+    """fp32 weight (M,C,KW) [OIK] or (C,M,KW) [IOK] -> packed bf16 image + (M, C, KW)."""
+    if w_layout == W_OIK:
+        M, C, KW = w.shape
+    else:
+        C, M, KW = w.shape
+    n = lib().alvq_packed_weight_elems(M, C, KW)
+    wp = torch.empty((n,), device=w.device, dtype=torch.bfloat16)
+    _check(lib().alvq_pack_weight_bf16(_ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout, _stream()), "alvq_pack_weight_bf16")
+    return wp, (M, C, KW)
+
+
+def relu_mask_bf16(dy, t):
+    out = nlc_like(dy, dy.C)
+    n = dy.rows * dy.Cp
+    _check(lib().alvq_relu_mask_bf16(dy.ptr, _nlc_ptr(t, dy, dy.C, "t"), out.ptr, n, _stream()), "alvq_relu_mask_bf16")
+    return out
+
+
+def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, out_ncl=False):
+    """x: NLC; packed = pack_weight(...).  Returns NLC y, (y, y2) with post, or a (B,M,L) fp32 tensor if out_ncl."""
+    wp, (M, C, KW) = packed
+    if C != x.C:
+        raise RuntimeError("conv1d_bf16: weight expects %d input channels, x has %d" % (C, x.C))
+    if bias is not None and bias.numel() != M:
+        raise RuntimeError("conv1d_bf16: bias has %d elements, expected %d" % (bias.numel(), M))
+    y = y2 = y_ncl = None
+    if out_ncl:
+        y_ncl = torch.empty((x.B, M, x.L), device=wp.device, dtype=torch.float32)
+    else:
+        y = nlc_like(x, M)
+        y2 = nlc_like(x, M) if post is not None else None
+    with _timed("conv1d_bf16_kernel", 2.0 * x.B * x.L * M * C * KW):
+        rc = lib().alvq_conv1d_bf16(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),
+                                    _nlc_ptr(skip2, x, M, "skip2"), _nlc_ptr(mask, x, M, "mask"),
+                                    _nlc_ptr(post, x, M, "post"), y.ptr if y is not None else None,
+                                    y2.ptr if y2 is not None else None, _ptr(y_ncl), x.B, C, M, x.L, KW,
+                                    int(bool(relu)), _stream())
+    _check(rc, "alvq_conv1d_bf16")
+    if out_ncl:
+        return y_ncl
+    return (y, y2) if post is not None else y
+
+
+def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, dbias_out=None, accumulate=False):
+    """dy, x: NLC.  fp32 dw in the weight's native layout (and dbias)."""
+    M, C = dy.C, x.C
+    shape = (M, C, KW) if w_layout == W_OIK else (C, M, KW)
+    dev = x.storage.device
+    if dw_out is None:
+        dw_out = torch.empty(shape, device=dev, dtype=torch.float32)
+        accumulate = False
+    elif tuple(dw_out.shape) != shape:
+        raise RuntimeError("conv1d_wgrad_bf16: dw_out has shape %s, expected %s" % (tuple(dw_out.shape), shape))
+    if want_bias and dbias_out is None:
+        dbias_out = torch.empty((M,), device=dev, dtype=torch.float32)
+    ws = _workspace(lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x.B, C, M, x.L, KW), dev)
+    with _timed("conv1d_wgrad_bf16_kernel", 2.0 * x.B * x.L * M * C * KW):
+        rc = lib().alvq_conv1d_wgrad_bf16(dy.ptr, x.ptr, _ptr(dw_out, name="dw"),
+                                          _ptr(dbias_out, name="dbias") if want_bias else None, ws.data_ptr(),
+                                          x.B, C, M, x.L, KW, w_layout, int(bool(accumulate)), _stream())
+    _check(rc, "alvq_conv1d_wgrad_bf16")
+    return (dw_out, dbias_out) if want_bias else dw_out

@@ -148,6 +148,41 @@ int alvq_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_av
  * ---------------------------------------------------------------------------------------------- */
 int alvq_stft_power_f32(const float* wave, float* power, int B, int S, int n_fft, int hop, void* stream);
 
+/* ================================================================================================
+ * bf16 throughput path (BASELINE configs[1]: "batch=64 bf16").  Storage bf16, accumulation fp32.
+ *
+ * Activations live in the "NLC-padded" layout: a bf16 matrix act[rows][Cp] with channels contiguous,
+ *   row(b,l) = 1 + b*(L+1) + l,   rows = alvq_nlc_rows(B,L) (rounded up to 128),   Cp = alvq_nlc_channels(C),
+ * row 0, the row after each sample, rows past the batch and channels >= C are zero.  The caller allocates
+ * alvq_nlc_guard_rows() readable rows before row 0 and after the last row; pointers passed below point at row 0.
+ * ============================================================================================== */
+int64_t alvq_nlc_rows(int B, int L);
+int alvq_nlc_channels(int C);
+int alvq_nlc_guard_rows(void);
+
+/* Re-pack an fp32 weight into the K-contiguous bf16 image the kernels read: wp[tap][Mp128][Cp] = A_t[m][c]
+ * (A_t as defined for alvq_conv1d_f32; zero padded).  wp holds alvq_packed_weight_elems(M,C,KW) bf16 values. */
+int64_t alvq_packed_weight_elems(int M, int C, int KW);
+int alvq_pack_weight_bf16(const float* w, void* wp, int M, int C, int KW, int w_layout, void* stream);
+
+/* (B,C,L) fp32 -> NLC-padded bf16 (the boundary conversion for x, quantized and incoming gradients). */
+int alvq_ncl_to_nlc_bf16(const float* x, void* y, int B, int C, int L, void* stream);
+
+/* out = t > 0 ? dy : 0 over n bf16 elements (n % 8 == 0). */
+int alvq_relu_mask_bf16(const void* dy, const void* t, void* out, int64_t n, void* stream);
+
+/* Same fused convolution as alvq_conv1d_f32 on NLC-padded bf16 operands and a packed weight.  Exactly one of
+ * y (NLC bf16, row stride alvq_nlc_channels(M)) and y_ncl ((B,M,L) fp32, bias-only epilogue) is non-NULL. */
+int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
+                     const void* mask, const void* post, void* y, void* y2, float* y_ncl,
+                     int B, int C, int M, int L, int KW, int relu, void* stream);
+
+/* Weight (and bias) gradient from NLC-padded bf16 dy [rows][Mp] and x [rows][Cp]; fp32 result in the weight's
+ * native layout, same contract as alvq_conv1d_wgrad_f32. */
+int64_t alvq_conv1d_wgrad_bf16_workspace_bytes(int B, int C, int M, int L, int KW);
+int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
+                           int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""bf16 throughput path, kernel level: the HIP kernels against a PyTorch-CPU statement that uses the SAME
+bf16-rounded operands with fp32 accumulation.  fp32 outputs agree to accumulation order (1e-5); bf16 outputs to
+one bf16 rounding (2^-8)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from acoustic_locating_vq_vae import _native as N  # noqa: E402
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def close_bf16(got, ref):
+    """|got - ref| <= one bf16 ulp of ref (plus accumulation-order slack)."""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    tol = ref.abs() * 2.0 ** -7 + 1e-6 * float(ref.abs().max())
+    return bool(((got - ref).abs() <= tol).all())
+
+
+SHAPES = [(2, 7, 16, 13, 3), (2, 16, 7, 13, 3), (2, 8, 16, 13, 1), (3, 5, 1, 201, 3), (2, 201, 1024, 500, 3),
+          (2, 1024, 128, 500, 3), (2, 1024, 1024, 201, 1), (2, 500, 1024, 201, 3), (2, 192, 1024, 77, 3),
+          (2, 1024, 201, 500, 3), (5, 130, 130, 129, 3), (1, 64, 64, 1, 3)]
+
+
+def test_layout_roundtrip_and_zero_padding():
+    torch.manual_seed(0)
+    x = torch.randn(3, 201, 37)
+    n = N.ncl_to_nlc(x.cuda())
+    assert n.Cp == 256 and n.rows == 128 and n.guard == 8
+    assert torch.equal(n.to_ncl().cpu(), bf(x))
+    m = n.matrix().float().cpu()
+    assert float(m[0].abs().sum()) == 0 and float(m[38].abs().sum()) == 0           # row 0 and the gap after sample 0
+    assert float(m[1 + 3 * 38:].abs().sum()) == 0 and float(m[:, 201:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B,C,M,L,KW", SHAPES)
+def test_conv_bf16_forward_both_layouts_and_outputs(B, C, M, L, KW):
+    torch.manual_seed(1)
+    x, b = torch.randn(B, C, L), torch.randn(M)
+    w = torch.randn(M, C, KW) / (C * KW) ** 0.5
+    ref = F.conv1d(bf(x), bf(w), b, padding=KW // 2)
+    xn = N.ncl_to_nlc(x.cuda())
+    pk = N.pack_weight(w.cuda(), N.W_OIK)
+    y32 = N.conv1d_bf16(xn, pk, b.cuda(), out_ncl=True)
+    assert rel(y32, ref) < 2e-5
+    y = N.conv1d_bf16(xn, pk, b.cuda())
+    assert close_bf16(y.to_ncl(), ref)
+    mat = y.matrix().float().cpu()
+    assert float(mat[0].abs().sum()) == 0 and float(mat[:, M:].abs().sum()) == 0 and float(mat[1 + B * (L + 1):].abs().sum()) == 0
+    assert float(mat[L + 1].abs().sum()) == 0                                        # gap rows stay zero
+    wt = torch.randn(C, M, KW) / (C * KW) ** 0.5
+    reft = F.conv_transpose1d(bf(x), bf(wt), b, padding=KW // 2)
+    yt = N.conv1d_bf16(xn, N.pack_weight(wt.cuda(), N.W_IOK), b.cuda(), out_ncl=True)
+    assert rel(yt, reft) < 2e-5
+
+
+def test_conv_bf16_epilogue_fusions():
+    torch.manual_seed(2)
+    B, C, M, L = 2, 24, 40, 50
+    x, w, b = torch.randn(B, C, L), torch.randn(M, C, 3) / 8, torch.randn(M)
+    s1, s2, mk, post = (torch.randn(B, M, L) for _ in range(4))
+    acc = F.conv1d(bf(x), bf(w), b, padding=1) + bf(s1) + bf(s2)
+    v = F.relu(acc)
+    v = torch.where(bf(mk) > 0, v, torch.zeros_like(v))
+    cu = lambda t: N.ncl_to_nlc(t.cuda())
+    y, y2 = N.conv1d_bf16(cu(x), N.pack_weight(w.cuda(), N.W_OIK), b.cuda(), cu(s1), cu(s2), cu(mk), cu(post), relu=True)
+    assert close_bf16(y.to_ncl(), v) and close_bf16(y2.to_ncl(), v + bf(post))
+
+
+@pytest.mark.parametrize("B,C,M,L,KW", SHAPES)
+def test_wgrad_bf16(B, C, M, L, KW):
+    torch.manual_seed(3)
+    x = bf(torch.randn(B, C, L)).requires_grad_(True)
+    w = (torch.randn(M, C, KW) / (C * KW) ** 0.5).requires_grad_(True)
+    b = torch.randn(M, requires_grad=True)
+    dy = bf(torch.randn(B, M, L))
+    F.conv1d(x, w, b, padding=KW // 2).backward(dy)
+    dw, db = N.conv1d_wgrad_bf16(N.ncl_to_nlc(dy.cuda()), N.ncl_to_nlc(x.detach().cuda()), KW, N.W_OIK, want_bias=True)
+    assert rel(dw, w.grad) < 3e-5
+    assert float((db.cpu() - b.grad).abs().max()) < 2e-6 * float(dy.abs().sum(dim=(0, 2)).max())
+    dw2 = N.conv1d_wgrad_bf16(N.ncl_to_nlc(dy.cuda()), N.ncl_to_nlc(x.detach().cuda()), KW, N.W_OIK, dw_out=dw.clone(), accumulate=True)
+    assert rel(dw2, 2 * w.grad) < 3e-5
+    # ConvTranspose weight layout
+    wt = (torch.randn(C, M, KW) / (C * KW) ** 0.5).requires_grad_(True)
+    F.conv_transpose1d(x.detach(), wt, None, padding=KW // 2).backward(dy)
+    dwt = N.conv1d_wgrad_bf16(N.ncl_to_nlc(dy.cuda()), N.ncl_to_nlc(x.detach().cuda()), KW, N.W_IOK)
+    assert rel(dwt, wt.grad) < 3e-5
+
+
+def test_relu_mask_bf16():
+    torch.manual_seed(4)
+    d, t = torch.randn(2, 70, 33), torch.randn(2, 70, 33)
+    out = N.relu_mask_bf16(N.ncl_to_nlc(d.cuda()), N.ncl_to_nlc(t.cuda()))
+    assert torch.equal(out.to_ncl().cpu(), torch.where(bf(t) > 0, bf(d), torch.zeros_like(d)))
