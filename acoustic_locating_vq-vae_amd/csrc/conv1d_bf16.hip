@@ -421,6 +421,27 @@ __global__ __launch_bounds__(256) void ncl_to_nlc_kernel(const float* x, u16* y,
   }
 }
 
+// NLC-padded bf16 -> (B,C,L) fp32 (for module outputs that leave the bf16 pipeline).
+__global__ __launch_bounds__(256) void nlc_to_ncl_kernel(const u16* x, float* y, int B, int C, int L, int Cp, int rows_total) {
+  __shared__ float tile[32][33];
+  const int ct = Cp / 32;
+  const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int Lp1 = L + 1, ndata = B * Lp1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // read: lanes along channels
+    const int row = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = row < rows_total ? bf2f(x[(long)row * Cp + c]) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // write: lanes along rows (l contiguous in the destination)
+    const int c = c0 + ty + 8 * i, row = r0 + tx;
+    int b, l;
+    if (row_valid(row, Lp1, ndata, &b, &l) && c < C) y[((long)b * C + c) * L + l] = tile[tx][ty + 8 * i];
+  }
+}
+
 // column sums of an NLC matrix: partial[s][m] = sum over the split's rows of dy[row][m]
 __global__ __launch_bounds__(256) void bias_grad_nlc_partial_kernel(const u16* dy, float* partial, int rows, int Mp,
                                                                     int rows_per_split) {
@@ -501,6 +522,15 @@ extern "C" int alvq_ncl_to_nlc_bf16(const float* x, void* y, int B, int C, int L
   hipLaunchKernelGGL(ncl_to_nlc_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y, B, C,
                      L, Cp, rows);
   return check_launch("alvq_ncl_to_nlc_bf16");
+}
+
+extern "C" int alvq_nlc_to_ncl_f32(const void* x, float* y, int B, int C, int L, void* stream) {
+  ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_nlc_to_ncl_f32: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_nlc_to_ncl_f32: bad dims");
+  const int Cp = pad_to(C, TB_K), rows = (int)alvq_nlc_rows(B, L);
+  hipLaunchKernelGGL(nlc_to_ncl_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, (const u16*)x, y, B,
+                     C, L, Cp, rows);
+  return check_launch("alvq_nlc_to_ncl_f32");
 }
 
 extern "C" int alvq_relu_mask_bf16(const void* dy, const void* t, void* out, int64_t n, void* stream) {

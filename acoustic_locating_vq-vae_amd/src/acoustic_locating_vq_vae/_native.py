@@ -53,6 +53,7 @@ _SIGNATURES = {
     "alvq_packed_weight_elems": (_i64, [_i32, _i32, _i32]),
     "alvq_pack_weight_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_ncl_to_nlc_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
+    "alvq_nlc_to_ncl_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_relu_mask_bf16": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
     "alvq_conv1d_bf16": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p]),
     "alvq_conv1d_wgrad_bf16_workspace_bytes": (_i64, [_i32] * 5),
@@ -394,6 +395,13 @@ def ncl_to_nlc(x):
     out = NLC(B, L, C, x.device)
     _check(lib().alvq_ncl_to_nlc_bf16(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16")
     return out
+
+
+def nlc_to_ncl(a):
+    """NLC bf16 -> (B,C,L) fp32 dense."""
+    y = torch.empty((a.B, a.C, a.L), device=a.storage.device, dtype=torch.float32)
+    _check(lib().alvq_nlc_to_ncl_f32(a.ptr, _ptr(y), a.B, a.C, a.L, _stream()), "alvq_nlc_to_ncl_f32")
+    return y
 
 
 def pack_weight(w, w_layout):

@@ -5,8 +5,19 @@ SURVEY App. B.2) no pre-activation value is ever consumed, so bias/skip/ReLU liv
 epilogue and the ReLU-backward masks live in the data-grad conv's epilogue.
 
 Notation follows SURVEY App. A:  t_r = relu(h_{r-1}),  u_r = relu(W1 *3 t_r),  h_r = t_r + W2 *1 u_r.
+
+Two precisions share these chains through a small "engine" object:
+
+* ``f32``  -- activations (B,C,L) fp32 exactly as the reference lays them out, exact-fp32 MFMA (parity mode);
+* ``bf16`` -- activations in the NLC-padded bf16 layout between convs, bf16 MFMA with fp32 accumulation
+  (BASELINE configs[1]); module inputs/outputs, the quantiser, losses, gradients of parameters and the
+  optimiser state stay fp32.
+
+Select with ``set_compute_dtype("f32" | "bf16")`` or the environment variable ``ALVQ_DTYPE`` (default f32).
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
@@ -14,6 +25,19 @@ import torch
 from . import _native as N
 
 OIK, IOK = N.W_OIK, N.W_IOK
+
+_DTYPE = os.environ.get("ALVQ_DTYPE", "f32")
+
+
+def set_compute_dtype(name):
+    global _DTYPE
+    if name not in ("f32", "bf16"):
+        raise ValueError("compute dtype must be 'f32' or 'bf16', got %r" % (name,))
+    _DTYPE = name
+
+
+def get_compute_dtype():
+    return _DTYPE
 
 
 def dense(x):
@@ -34,35 +58,134 @@ def _need_gpu(x, who):
 
 
 # --------------------------------------------------------------------------------------------------
+# precision engines
+# --------------------------------------------------------------------------------------------------
+class _F32Engine:
+    name = "f32"
+
+    def enter(self, x):
+        return dense(x)
+
+    def leave(self, a):
+        return a
+
+    def conv(self, x, w, layout=OIK, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, out_f32=False):
+        return N.conv1d(x, w, bias, skip1, skip2, mask, post, relu, layout)
+
+    def wgrad(self, dy, x, kw, layout, want_bias=False, dw_out=None):
+        return N.conv1d_wgrad(dy, x, kw, layout, want_bias=want_bias, dw_out=dw_out, accumulate=dw_out is not None)
+
+    def relu_mask(self, dy, t):
+        return N.relu_mask(dy, t)
+
+    def pack(self, act):
+        return act, None
+
+    def unpack(self, tensor, meta):
+        return tensor
+
+
+class _BF16Engine:
+    name = "bf16"
+
+    def __init__(self):
+        self._packed = {}
+
+    def _w(self, w, layout):
+        key = (w.data_ptr(), layout)
+        pk = self._packed.get(key)
+        if pk is None:
+            pk = self._packed[key] = N.pack_weight(w.detach(), layout)
+        return pk
+
+    def enter(self, x):
+        return N.ncl_to_nlc(dense(x))
+
+    def leave(self, a):
+        return N.nlc_to_ncl(a)
+
+    def conv(self, x, w, layout=OIK, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, out_f32=False):
+        return N.conv1d_bf16(x, self._w(w, layout), bias, skip1, skip2, mask, post, relu, out_ncl=out_f32)
+
+    def wgrad(self, dy, x, kw, layout, want_bias=False, dw_out=None):
+        return N.conv1d_wgrad_bf16(dy, x, kw, layout, want_bias=want_bias, dw_out=dw_out, accumulate=dw_out is not None)
+
+    def relu_mask(self, dy, t):
+        return N.relu_mask_bf16(dy, t)
+
+    def pack(self, act):
+        return act.storage, (act.B, act.L, act.C)
+
+    def unpack(self, tensor, meta):
+        return N.NLC.wrap(tensor, *meta)
+
+
+def _engine(name=None):
+    return _BF16Engine() if (name or _DTYPE) == "bf16" else _F32Engine()
+
+
+def _save(ctx, eng, tensors, acts):
+    """save_for_backward(*tensors, *activation storages) + remember how to re-wrap the activations."""
+    packed = [eng.pack(a) for a in acts]
+    ctx.eng_name = eng.name
+    ctx.n_plain = len(tensors)
+    ctx.act_meta = [m for _, m in packed]
+    ctx.save_for_backward(*tensors, *[t for t, _ in packed])
+
+
+def _load(ctx):
+    eng = _engine(ctx.eng_name)
+    saved = ctx.saved_tensors
+    plain = saved[:ctx.n_plain]
+    acts = [eng.unpack(t, m) for t, m in zip(saved[ctx.n_plain:], ctx.act_meta)]
+    return eng, plain, acts
+
+
+# --------------------------------------------------------------------------------------------------
 # residual stack (shared W1, W2 used R times; residual_stack.py:40-46)
 # --------------------------------------------------------------------------------------------------
-def _stack_forward(t1, w1, w2, R, post=None):
+def _stack_forward(eng, t1, w1, w2, R, post=None):
     """t1 = relu(h0).  Returns (ts[1..R+1], us[1..R], out) where out = ts[R+1] (+ post)."""
     ts, us = [t1], []
     out = None
     for r in range(R):
-        u = N.conv1d(ts[-1], w1, relu=True)
+        u = eng.conv(ts[-1], w1, relu=True)
         us.append(u)
         if r == R - 1 and post is not None:
-            t, out = N.conv1d(u, w2, skip1=ts[-1], relu=True, post=post)
+            t, out = eng.conv(u, w2, skip1=ts[-1], relu=True, post=post)
         else:
-            t = N.conv1d(u, w2, skip1=ts[-1], relu=True)
+            t = eng.conv(u, w2, skip1=ts[-1], relu=True)
         ts.append(t)
     if out is None:
         out = ts[-1]
     return ts, us, out
 
 
-def _stack_backward(dh, ts, us, w1, w2, R, outer=None):
+def _stack_backward(eng, dh, ts, us, w1, w2, R, outer=None):
     """dh = grad wrt h_R, already masked by (t_{R+1} > 0).  outer = extra grad flowing into t_1 (encoder skip).
-    Returns (dh0 masked by t_1>0, dW1, dW2)."""
+    Returns (dh0 masked by t_1>0, dW1, dW2) with the R uses of the shared weights summed in a fixed order."""
     dw1 = dw2 = None
     for r in range(R - 1, -1, -1):
-        du = N.conv1d(dh, w2, mask=us[r], w_layout=IOK)                       # k1 data-grad, * (u_r > 0)
-        dw2 = N.conv1d_wgrad(dh, us[r], 1, OIK, dw_out=dw2, accumulate=dw2 is not None)
-        dw1 = N.conv1d_wgrad(du, ts[r], 3, OIK, dw_out=dw1, accumulate=dw1 is not None)
-        dh = N.conv1d(du, w1, skip1=dh, skip2=outer if r == 0 else None, mask=ts[r], w_layout=IOK)
+        du = eng.conv(dh, w2, IOK, mask=us[r])                                 # k1 data-grad, * (u_r > 0)
+        dw2 = eng.wgrad(dh, us[r], 1, OIK, dw_out=dw2)
+        dw1 = eng.wgrad(du, ts[r], 3, OIK, dw_out=dw1)
+        dh = eng.conv(du, w1, IOK, skip1=dh, skip2=outer if r == 0 else None, mask=ts[r])
     return dh, dw1, dw2
+
+
+def _encoder_forward(eng, x, wc, bc, w1, w2, R):
+    xi = eng.enter(x)
+    t1 = eng.conv(xi, wc, bias=bc, relu=True)
+    ts, us, out = _stack_forward(eng, t1, w1, w2, R, post=t1)
+    return xi, ts, us, out
+
+
+def _encoder_backward(eng, d_out, xi, ts, us, wc, w1, w2, R, need_dx):
+    dh = eng.relu_mask(d_out, ts[R])                                             # * (h_R > 0)
+    dh0, dw1, dw2 = _stack_backward(eng, dh, ts, us, w1, w2, R, outer=d_out)
+    dwc, dbc = eng.wgrad(dh0, xi, 3, OIK, want_bias=True)
+    dx = eng.conv(dh0, wc, IOK, out_f32=True) if need_dx else None
+    return dx, dwc, dbc, dw1, dw2
 
 
 class EncoderFn(torch.autograd.Function):
@@ -70,25 +193,44 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wc, bc, w1, w2, R):
-        x = dense(x)
-        t1 = N.conv1d(x, wc, bc, relu=True)
-        ts, us, out = _stack_forward(t1, w1, w2, R, post=t1)
+        eng = _engine()
+        xi, ts, us, out = _encoder_forward(eng, x, wc, bc, w1, w2, R)
         ctx.R = R
-        ctx.save_for_backward(x, wc, w1, w2, *ts, *us)
-        return out
+        _save(ctx, eng, (wc, w1, w2), [xi, *ts, *us])
+        return eng.leave(out)
 
     @staticmethod
     def backward(ctx, d_out):
         R = ctx.R
-        saved = ctx.saved_tensors
-        x, wc, w1, w2 = saved[:4]
-        ts, us = saved[4:4 + R + 1], saved[5 + R:5 + 2 * R]
-        d_out = d_out.contiguous()
-        dh = N.relu_mask(d_out, ts[R])                                          # * (h_R > 0)
-        dh0, dw1, dw2 = _stack_backward(dh, ts, us, w1, w2, R, outer=d_out)
-        dwc, dbc = N.conv1d_wgrad(dh0, x, 3, OIK, want_bias=True)
-        dx = N.conv1d(dh0, wc, w_layout=IOK) if ctx.needs_input_grad[0] else None
+        eng, (wc, w1, w2), acts = _load(ctx)
+        xi, ts, us = acts[0], acts[1:R + 2], acts[R + 2:]
+        dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, eng.enter(d_out), xi, ts, us, wc, w1, w2, R, ctx.needs_input_grad[0])
         return dx, dwc, dbc, dw1, dw2, None
+
+
+class LatentFn(torch.autograd.Function):
+    """Encoder + ``_pre_vq_conv`` (convolutional_vq_vae.py:94-95) as one node: z = W_pre *3 encoder(x) + b_pre,
+    returned as dense (B,D,L) fp32 because the quantiser slices that buffer in memory order."""
+
+    @staticmethod
+    def forward(ctx, x, wc, bc, w1, w2, wp, bp, R):
+        eng = _engine()
+        xi, ts, us, out = _encoder_forward(eng, x, wc, bc, w1, w2, R)
+        z = eng.conv(out, wp, bias=bp, out_f32=True)
+        ctx.R = R
+        _save(ctx, eng, (wc, w1, w2, wp), [xi, out, *ts, *us])
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        R = ctx.R
+        eng, (wc, w1, w2, wp), acts = _load(ctx)
+        xi, out, ts, us = acts[0], acts[1], acts[2:R + 3], acts[R + 3:]
+        dzi = eng.enter(dz)
+        d_out = eng.conv(dzi, wp, IOK)
+        dwp, dbp = eng.wgrad(dzi, out, 3, OIK, want_bias=True)
+        dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, d_out, xi, ts, us, wc, w1, w2, R, ctx.needs_input_grad[0])
+        return dx, dwc, dbc, dw1, dw2, dwp, dbp, None
 
 
 class StackFn(torch.autograd.Function):
@@ -96,22 +238,22 @@ class StackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h0, w1, w2, R):
-        h0 = dense(h0)
-        t1 = N.relu_mask(h0, h0)
-        ts, us, out = _stack_forward(t1, w1, w2, R)
+        eng = _engine()
+        hi = eng.enter(h0)
+        t1 = eng.relu_mask(hi, hi)
+        ts, us, out = _stack_forward(eng, t1, w1, w2, R)
         ctx.R = R
-        ctx.save_for_backward(w1, w2, *ts, *us)
-        return out
+        _save(ctx, eng, (w1, w2), [*ts, *us])
+        return eng.leave(out)
 
     @staticmethod
     def backward(ctx, d_out):
         R = ctx.R
-        saved = ctx.saved_tensors
-        w1, w2 = saved[:2]
-        ts, us = saved[2:2 + R + 1], saved[3 + R:3 + 2 * R]
-        dh = N.relu_mask(d_out.contiguous(), ts[R])
-        dh0, dw1, dw2 = _stack_backward(dh, ts, us, w1, w2, R)
-        return dh0, dw1, dw2, None
+        eng, (w1, w2), acts = _load(ctx)
+        ts, us = acts[:R + 1], acts[R + 1:]
+        dh = eng.relu_mask(eng.enter(d_out), ts[R])
+        dh0, dw1, dw2 = _stack_backward(eng, dh, ts, us, w1, w2, R)
+        return eng.leave(dh0), dw1, dw2, None
 
 
 class ResidualLayerFn(torch.autograd.Function):
@@ -119,49 +261,50 @@ class ResidualLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, w2):
-        x = dense(x)
-        t = N.relu_mask(x, x)
-        u = N.conv1d(t, w1, relu=True)
-        ctx.save_for_backward(w1, w2, t, u)
-        return N.conv1d(u, w2, skip1=t)
+        eng = _engine()
+        xi = eng.enter(x)
+        t = eng.relu_mask(xi, xi)
+        u = eng.conv(t, w1, relu=True)
+        _save(ctx, eng, (w1, w2), [t, u])
+        return eng.leave(eng.conv(u, w2, skip1=t))
 
     @staticmethod
     def backward(ctx, dy):
-        w1, w2, t, u = ctx.saved_tensors
-        dy = dy.contiguous()
-        du = N.conv1d(dy, w2, mask=u, w_layout=IOK)
-        dw2 = N.conv1d_wgrad(dy, u, 1, OIK)
-        dw1 = N.conv1d_wgrad(du, t, 3, OIK)
-        dx = N.conv1d(du, w1, skip1=dy, mask=t, w_layout=IOK)
-        return dx, dw1, dw2
+        eng, (w1, w2), (t, u) = _load(ctx)
+        dyi = eng.enter(dy)
+        du = eng.conv(dyi, w2, IOK, mask=u)
+        dw2 = eng.wgrad(dyi, u, 1, OIK)
+        dw1 = eng.wgrad(du, t, 3, OIK)
+        dx = eng.conv(du, w1, IOK, skip1=dyi, mask=t)
+        return eng.leave(dx), dw1, dw2
 
 
 class ConvFn(torch.autograd.Function):
-    """Plain Conv1d / ConvTranspose1d (k in {1,3}, stride 1, same padding) with bias
-    (convolutional_vq_vae.py:32-37,95)."""
+    """Plain Conv1d / ConvTranspose1d (k in {1,3}, stride 1, same padding) with bias, fp32 in / fp32 out."""
 
     @staticmethod
     def forward(ctx, x, w, b, layout):
-        x = dense(x)
+        eng = _engine()
+        xi = eng.enter(x)
         ctx.layout = layout
-        ctx.save_for_backward(x, w)
-        return N.conv1d(x, w, b, w_layout=layout)
+        _save(ctx, eng, (w,), [xi])
+        return eng.conv(xi, w, layout, bias=b, out_f32=True)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = dy.contiguous()
+        eng, (w,), (xi,) = _load(ctx)
+        dyi = eng.enter(dy)
         kw = w.shape[2]
         if ctx.needs_input_grad[2]:
-            dw, db = N.conv1d_wgrad(dy, x, kw, ctx.layout, want_bias=True)
+            dw, db = eng.wgrad(dyi, xi, kw, ctx.layout, want_bias=True)
         else:
-            dw, db = N.conv1d_wgrad(dy, x, kw, ctx.layout), None
-        dx = N.conv1d(dy, w, w_layout=IOK if ctx.layout == OIK else OIK) if ctx.needs_input_grad[0] else None
+            dw, db = eng.wgrad(dyi, xi, kw, ctx.layout), None
+        dx = eng.conv(dyi, w, IOK if ctx.layout == OIK else OIK, out_f32=True) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None
 
 
 class JitterFn(torch.autograd.Function):
-    """Jitter (modules/jitter.py:42-70) with a host-drawn source-index vector."""
+    """Jitter (modules/jitter.py:42-70) with a host-drawn source-index vector (always fp32 (B,C,L))."""
 
     @staticmethod
     def forward(ctx, q, src):
@@ -175,48 +318,47 @@ class JitterFn(torch.autograd.Function):
 
 
 class DecoderFn(torch.autograd.Function):
-    """DeconvolutionalDecoder.forward (deconvolutional_decoder.py:62-79)."""
+    """DeconvolutionalDecoder.forward (deconvolutional_decoder.py:62-79): fp32 (B,D,L) in, fp32 (B,out,L) out."""
 
     @staticmethod
     def forward(ctx, q, src, wd, bd, w1, w2, wt1, bt1, wt2, bt2, wt3, bt3, R):
+        eng = _engine()
         q = dense(q)
-        qj = N.jitter_gather(q, src) if src is not None else q
-        t1 = N.conv1d(qj, wd, bd, relu=True)
-        ts, us, top = _stack_forward(t1, w1, w2, R)
-        a1 = N.conv1d(top, wt1, bt1, relu=True, w_layout=IOK)
-        a2 = N.conv1d(a1, wt2, bt2, relu=True, w_layout=IOK)
-        y = N.conv1d(a2, wt3, bt3, w_layout=IOK)
+        qj = eng.enter(N.jitter_gather(q, src) if src is not None else q)
+        t1 = eng.conv(qj, wd, bias=bd, relu=True)
+        ts, us, top = _stack_forward(eng, t1, w1, w2, R)
+        a1 = eng.conv(top, wt1, IOK, bias=bt1, relu=True)
+        a2 = eng.conv(a1, wt2, IOK, bias=bt2, relu=True)
+        y = eng.conv(a2, wt3, IOK, bias=bt3, out_f32=True)
         ctx.R = R
-        ctx.has_src = src is not None
-        extra = (src,) if src is not None else ()
-        ctx.save_for_backward(qj, wd, w1, w2, wt1, wt2, wt3, a1, a2, *ts, *us, *extra)
+        ctx.src = src
+        _save(ctx, eng, (wd, w1, w2, wt1, wt2, wt3), [qj, a1, a2, *ts, *us])
         return y
 
     @staticmethod
     def backward(ctx, dy):
         R = ctx.R
-        saved = ctx.saved_tensors
-        qj, wd, w1, w2, wt1, wt2, wt3, a1, a2 = saved[:9]
-        ts, us = saved[9:9 + R + 1], saved[10 + R:10 + 2 * R]
-        dy = dy.contiguous()
-        da2 = N.conv1d(dy, wt3, mask=a2, w_layout=OIK)                         # convT data-grad, * (a2 > 0)
-        dwt3, dbt3 = N.conv1d_wgrad(dy, a2, 3, IOK, want_bias=True)
-        da1 = N.conv1d(da2, wt2, mask=a1, w_layout=OIK)
-        dwt2, dbt2 = N.conv1d_wgrad(da2, a1, 3, IOK, want_bias=True)
-        dh = N.conv1d(da1, wt1, mask=ts[R], w_layout=OIK)                      # * (h_R > 0)
-        dwt1, dbt1 = N.conv1d_wgrad(da1, ts[R], 3, IOK, want_bias=True)
-        dh0, dw1, dw2 = _stack_backward(dh, ts, us, w1, w2, R)
-        dwd, dbd = N.conv1d_wgrad(dh0, qj, 3, OIK, want_bias=True)
+        eng, (wd, w1, w2, wt1, wt2, wt3), acts = _load(ctx)
+        qj, a1, a2, ts, us = acts[0], acts[1], acts[2], acts[3:R + 4], acts[R + 4:]
+        dyi = eng.enter(dy)
+        da2 = eng.conv(dyi, wt3, OIK, mask=a2)                                   # convT data-grad, * (a2 > 0)
+        dwt3, dbt3 = eng.wgrad(dyi, a2, 3, IOK, want_bias=True)
+        da1 = eng.conv(da2, wt2, OIK, mask=a1)
+        dwt2, dbt2 = eng.wgrad(da2, a1, 3, IOK, want_bias=True)
+        dh = eng.conv(da1, wt1, OIK, mask=ts[R])                                 # * (h_R > 0)
+        dwt1, dbt1 = eng.wgrad(da1, ts[R], 3, IOK, want_bias=True)
+        dh0, dw1, dw2 = _stack_backward(eng, dh, ts, us, w1, w2, R)
+        dwd, dbd = eng.wgrad(dh0, qj, 3, OIK, want_bias=True)
         dq = None
         if ctx.needs_input_grad[0]:
-            dq = N.conv1d(dh0, wd, w_layout=IOK)
-            if ctx.has_src:
-                dq = N.jitter_gather(dq, saved[-1], backward=True)
+            dq = eng.conv(dh0, wd, IOK, out_f32=True)
+            if ctx.src is not None:
+                dq = N.jitter_gather(dq, ctx.src, backward=True)
         return dq, None, dwd, dbd, dw1, dw2, dwt1, dbt1, dwt2, dbt2, dwt3, dbt3, None
 
 
 class VQFn(torch.autograd.Function):
-    """VectorQuantizer.forward (vector_quantizer.py:29-58) -> (loss, q_st, perplexity, idx)."""
+    """VectorQuantizer.forward (vector_quantizer.py:29-58) -> (loss, q_st, perplexity, idx).  Always fp32."""
 
     @staticmethod
     def forward(ctx, z, codebook, beta, train_vq):

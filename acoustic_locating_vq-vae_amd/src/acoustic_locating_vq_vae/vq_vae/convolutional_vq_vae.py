@@ -37,9 +37,13 @@ class ConvolutionalVQVAE(nn.Module):
         return self._vq.get_embedding_dim()
 
     def _latent(self, x):
-        z = self._encoder(x)
-        z = _ops.ConvFn.apply(z, self._pre_vq_conv.weight, self._pre_vq_conv.bias, _ops.OIK)
-        return z
+        """``_pre_vq_conv(_encoder(x))`` (:94-95) as one autograd node (the encoder output never leaves the
+        compute layout between the two)."""
+        _ops._need_gpu(x, "ConvolutionalVQVAE")
+        enc, pre = self._encoder, self._pre_vq_conv
+        w1, w2 = enc._residual_stack.weights
+        return _ops.LatentFn.apply(x, enc._conv_1.weight, enc._conv_1.bias, w1, w2, pre.weight, pre.bias,
+                                   enc._residual_stack._num_residual_layers)
 
     def forward(self, x):
         z = self._latent(x)

@@ -26,6 +26,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 matrix rate (= vector rate)
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (NOT the 2:1-sparsity headline)
+PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS}
+CONV_FAMILY = {"f32": "conv1d_f32_kernel", "bf16": "conv1d_bf16_kernel"}
 SPEECH_CFG = (201, 1024, 128, 3, 1024, 0.25, 1024)          # scripts/train_speech.py:152-153
 RIR_CFG = (500, 1024, 64, 2, 64, 0.25, 1024)                # scripts/train_rir.py:147-149
 
@@ -77,6 +80,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU")
     ap.add_argument("--config", default="speech", choices=["speech", "rir"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
+                    help="bf16: BASELINE configs[1] (bf16 storage/MFMA, fp32 accumulate+master weights); f32: parity mode")
+    ap.add_argument("--no-f32-line", action="store_true", help="skip the secondary fp32 parity-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -93,9 +99,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from acoustic_locating_vq_vae import _native as N
+    from acoustic_locating_vq_vae import _ops
     from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
     from acoustic_locating_vq_vae.train_step import Trainer
 
+    _ops.set_compute_dtype(args.dtype)
     torch.manual_seed(0)                         # identical init on every rank (also broadcast by Trainer)
     np.random.seed(1234 + rank)                  # jitter: per-rank numpy stream
     B = args.batch
@@ -119,25 +127,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = trainer.step(raw, wiener)
-    barrier()
-    timer = None if args.no_kernel_timer else N.KernelTimer()
-    if timer is not None:
-        timer.__enter__()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = trainer.step(raw, wiener)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if timer is not None:
-        timer.__exit__()
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss = float(out[0])
-    assert np.isfinite(loss), "non-finite loss"
+    def measure(steps, warmup, use_timer):
+        for _ in range(warmup):
+            out = trainer.step(raw, wiener)
+        barrier()
+        timer = N.KernelTimer() if use_timer else None
+        if timer is not None:
+            timer.__enter__()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = trainer.step(raw, wiener)
+        barrier()
+        dt = time.perf_counter() - t0
+        if timer is not None:
+            timer.__exit__()
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        last = float(out[0])
+        assert np.isfinite(last), "non-finite loss"
+        return dt, last, (timer.summary() if timer is not None else None)
+
+    def roofline(summ, dtype, steps):
+        fam = CONV_FAMILY[dtype]
+        n, secs, flops = summ[fam]
+        ach = flops / secs / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(fam)
+        return {"bound": "mfma", "kernel": fam, "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s",
+                "frac": ach / PEAK[dtype], "traffic": traffic, "launches": n, "avg_launch_ms": 1e3 * secs / n,
+                "algorithmic_gflop_per_launch": flops / n / 1e9}
+
+    def families(summ, steps):
+        return {k: {"launches": v[0], "ms_per_step": 1e3 * v[1] / steps, "tflops": (v[2] / v[1] / 1e12) if v[1] > 0 else None}
+                for k, v in summ.items()}
+
+    elapsed, loss, summ = measure(args.steps, args.warmup, not args.no_kernel_timer)
 
     if rank == 0:
         gf = algorithmic_gflop_per_spectrogram(cfg, L, oc)
@@ -146,32 +174,33 @@ def main():
             "metric": "spectrograms/sec (train step), speech VQ-VAE default config",
             "value": value, "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s VQ-VAE train step (fwd+bwd+Adam), ctor %s, B=%d per GPU x (%s) fp32, jitter %s"
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s VQ-VAE train step (fwd+bwd+Adam), ctor %s, B=%d per GPU x (%s), %s, jitter %s"
                                    % (kind, list(cfg), B, "201,500" if kind == "speech" else "500,201",
+                                      "bf16 storage + bf16 MFMA, fp32 accumulate / VQ / losses / master weights"
+                                      if args.dtype == "bf16" else "fp32 storage + exact-fp32 MFMA",
                                       "on" if kind == "speech" else "off"),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "algorithmic_gflop_per_spectrogram": gf},
             "model_tflops": value * gf / 1e3,
             "final_loss": loss,
         }
-        if timer is not None:
-            summ = timer.summary()
-            fam = "conv1d_f32_kernel"
-            if fam in summ:
-                n, secs, flops = summ[fam]
-                ach = flops / secs / 1e12
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "traffic.json")
-                if os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get(fam)
-                line["roofline"] = {"bound": "mfma", "kernel": fam, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                                    "launches": n, "avg_launch_ms": 1e3 * secs / n,
-                                    "algorithmic_gflop_per_launch": flops / n / 1e9}
-            line["kernel_families"] = {k: {"launches": v[0], "ms_per_step": 1e3 * v[1] / args.steps,
-                                           "tflops": (v[2] / v[1] / 1e12) if v[1] > 0 else None}
-                                       for k, v in summ.items()}
+        if summ is not None:
+            line["roofline"] = roofline(summ, args.dtype, args.steps)
+            line["kernel_families"] = families(summ, args.steps)
+    if args.dtype == "bf16" and not args.no_f32_line:
+        # secondary line: the fp32 parity mode (exact-fp32 MFMA, reference layout) on the same model and batch
+        _ops.set_compute_dtype("f32")
+        s2 = max(3, min(5, args.steps))
+        e2, l2, summ2 = measure(s2, 2, not args.no_kernel_timer)
+        _ops.set_compute_dtype(args.dtype)
+        if rank == 0:
+            v2 = world * B * s2 / e2
+            line["f32_parity_mode"] = {"value": v2, "unit": "spectrograms/s", "ms_per_step": 1e3 * e2 / s2, "steps": s2,
+                                       "model_tflops": v2 * gf / 1e3}
+            if summ2 is not None:
+                line["f32_parity_mode"]["roofline"] = roofline(summ2, "f32", s2)
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

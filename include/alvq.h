@@ -168,6 +168,9 @@ int alvq_pack_weight_bf16(const float* w, void* wp, int M, int C, int KW, int w_
 /* (B,C,L) fp32 -> NLC-padded bf16 (the boundary conversion for x, quantized and incoming gradients). */
 int alvq_ncl_to_nlc_bf16(const float* x, void* y, int B, int C, int L, void* stream);
 
+/* NLC-padded bf16 -> (B,C,L) fp32. */
+int alvq_nlc_to_ncl_f32(const void* x, float* y, int B, int C, int L, void* stream);
+
 /* out = t > 0 ? dy : 0 over n bf16 elements (n % 8 == 0). */
 int alvq_relu_mask_bf16(const void* dy, const void* t, void* out, int64_t n, void* stream);
 
