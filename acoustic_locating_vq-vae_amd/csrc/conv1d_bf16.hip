@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void relu_mask_bf16_kernel(const u16* dy, cons
 static int wgrad_b_splits(int total_rows, int M, int C, int* chunks_per_split) {
   const int nchunks = (total_rows + WG_R - 1) / WG_R;
   const int tiles = ((M + WG_M - 1) / WG_M) * ((C + WG_C - 1) / WG_C);
-  int want = (1536 + tiles - 1) / tiles;
+  int want = (512 + tiles - 1) / tiles;  // one full wave of workgroups (2 per CU); keeps the partial slab small
   if (want < 1) want = 1;
   if (want > nchunks) want = nchunks;
   if (want > 64) want = 64;

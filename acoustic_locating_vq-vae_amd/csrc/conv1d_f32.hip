@@ -364,7 +364,7 @@ static int wgrad_splits(int B, int C, int M, int L, int KW, int* chunks_per_spli
   const long V = (long)B * (L + PAD);
   const int nchunks = (int)((V + GV - 1) / GV);
   const int tiles = ((M + GM - 1) / GM) * ((C + GC - 1) / GC);
-  int want = (1536 + tiles - 1) / tiles;  // ~6 workgroups per CU
+  int want = (512 + tiles - 1) / tiles;  // one full wave of workgroups (2 per CU); keeps the partial slab small
   if (want < 1) want = 1;
   if (want > nchunks) want = nchunks;
   if (want > 64) want = 64;

@@ -139,6 +139,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   }
 }
 
+// Same arithmetic with the step-dependent scalars read from device memory, so a captured hipGraph can be
+// replayed every step: sc = {lr/bias_correction1, sqrt(bias_correction2), grad_scale}.
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, long n, const float* sc,
+                                                       float beta1, float beta2, float eps) {
+  const float lr_bc1 = sc[0], bc2_sqrt = sc[1], gscale = sc[2];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float gr = g[e] * gscale;
+    const float mm = m[e] + (gr - m[e]) * (1.f - beta1);
+    const float vv = v[e] * beta2 + (1.f - beta2) * gr * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    m[e] = mm;
+    v[e] = vv;
+    p[e] = p[e] - lr_bc1 * (mm / denom);
+  }
+}
+
 }  // namespace alvq
 
 using namespace alvq;
@@ -216,4 +232,13 @@ extern "C" int alvq_adam_f32(float* param, const float* grad, float* exp_avg, fl
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
                      (long)n, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
   return check_launch("alvq_adam_f32");
+}
+
+extern "C" int alvq_adam_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 const float* scalars, float beta1, float beta2, float eps, void* stream) {
+  ALVQ_REQUIRE(param && grad && exp_avg && exp_avg_sq && scalars, ALVQ_EINVAL, "alvq_adam_dev_f32: null pointer");
+  ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_adam_dev_f32: n <= 0");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                     (long)n, scalars, beta1, beta2, eps);
+  return check_launch("alvq_adam_dev_f32");
 }

@@ -172,8 +172,18 @@ __global__ __launch_bounds__(256) void vq_gather_loss_kernel(const float* x, con
                                                              float* q_st, float* partials, int32_t* hist, long N, int K,
                                                              int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // consecutive rows per workgroup (coalesced), histogram privatised in LDS when it fits (hot codes would
+  // otherwise serialise on one global counter)
+  extern __shared__ int lhist[];
+  const bool use_lds = hist && K <= 8192;
+  if (use_lds) {
+    for (int k = threadIdx.x; k < K; k += 256) lhist[k] = 0;
+    __syncthreads();
+  }
+  const long per = (N + gridDim.x - 1) / gridDim.x;
+  const long rb = (long)blockIdx.x * per, re = rb + per < N ? rb + per : N;
   float s = 0.f;
-  for (long r = (long)blockIdx.x * 4 + wave; r < N; r += (long)gridDim.x * 4) {
+  for (long r = rb + wave; r < re; r += 4) {
     const long k = idx[r];
     for (int d = lane; d < D; d += 64) {
       const float xv = x[r * D + d];
@@ -181,7 +191,12 @@ __global__ __launch_bounds__(256) void vq_gather_loss_kernel(const float* x, con
       q_st[r * D + d] = xv + diff;
       s += diff * diff;
     }
-    if (lane == 0 && hist) atomicAdd(&hist[k], 1);
+    if (lane == 0 && hist) atomicAdd(use_lds ? &lhist[k] : &hist[k], 1);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256)
+      if (lhist[k]) atomicAdd(&hist[k], lhist[k]);
   }
   s = wave_sum(s);
   __shared__ float red[4];
@@ -292,8 +307,8 @@ extern "C" int alvq_vq_gather_loss_f32(const float* x, const float* codebook, co
                                        float* sq_partials, int32_t* hist, int64_t N, int K, int D, void* stream) {
   ALVQ_REQUIRE(x && codebook && idx && q_st && sq_partials, ALVQ_EINVAL, "alvq_vq_gather_loss_f32: null pointer");
   ALVQ_REQUIRE(N > 0 && K > 0 && D > 0, ALVQ_EINVAL, "alvq_vq_gather_loss_f32: bad dims");
-  hipLaunchKernelGGL(vq_gather_loss_kernel, dim3(VQ_PARTIALS), dim3(256), 0, (hipStream_t)stream, x, codebook, idx,
-                     q_st, sq_partials, hist, (long)N, K, D);
+  hipLaunchKernelGGL(vq_gather_loss_kernel, dim3(VQ_PARTIALS), dim3(256), (hist && K <= 8192) ? K * sizeof(int) : 0,
+                     (hipStream_t)stream, x, codebook, idx, q_st, sq_partials, hist, (long)N, K, D);
   return check_launch("alvq_vq_gather_loss_f32");
 }
 

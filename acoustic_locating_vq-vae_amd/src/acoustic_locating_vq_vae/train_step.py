@@ -81,7 +81,11 @@ class FlatBuffers:
 
 
 class FlatAdam:
-    """Adam over FlatBuffers as one HIP kernel launch (alvq_adam_f32)."""
+    """Adam over FlatBuffers as one HIP kernel launch.
+
+    The step-dependent scalars (lr/bias_correction1, sqrt(bias_correction2), grad_scale) live in a 3-float
+    device buffer that ``prepare()`` refreshes from pinned host memory, so ``apply()`` -- the launch itself --
+    can sit inside a captured hipGraph and be replayed every step."""
 
     def __init__(self, buffers: FlatBuffers, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.b = buffers
@@ -89,11 +93,26 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(buffers.flat)
         self.exp_avg_sq = torch.zeros_like(buffers.flat)
         self.step_count = 0
+        self.scalars = torch.zeros(3, device=buffers.flat.device, dtype=torch.float32)
+        self._host = torch.zeros(3, dtype=torch.float32)
+        if buffers.flat.is_cuda:
+            self._host = self._host.pin_memory()
+
+    def prepare(self, grad_scale=1.0):
+        self.step_count += 1
+        b1, b2 = self.betas
+        self._host[0] = self.lr / (1.0 - b1 ** self.step_count)
+        self._host[1] = (1.0 - b2 ** self.step_count) ** 0.5
+        self._host[2] = grad_scale
+        self.scalars.copy_(self._host, non_blocking=True)
+
+    def apply(self):
+        N.adam_step_dev(self.b.flat, self.b.grad, self.exp_avg, self.exp_avg_sq, self.scalars, self.betas[0],
+                        self.betas[1], self.eps)
 
     def step(self, grad_scale=1.0):
-        self.step_count += 1
-        N.adam_step(self.b.flat, self.b.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                    self.betas[0], self.betas[1], self.eps, grad_scale)
+        self.prepare(grad_scale)
+        self.apply()
 
 
 def shard_batch(x, rank, world):
@@ -123,6 +142,9 @@ class Trainer:
         self.buffers = FlatBuffers(params)
         self.buffers.broadcast_params(group=group)
         self.opt = FlatAdam(self.buffers, lr=lr)
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.grad_scale = 1.0 / world
+        self._graph = None
 
     def preprocess(self, raw, wiener=None):
         if self.kind == "speech":
@@ -145,12 +167,59 @@ class Trainer:
         recon_error = _ops.MSEFn.apply(recon, target)
         return recon_error + vq_loss, recon_error, perplexity
 
-    def step(self, raw, wiener=None):
-        """Returns (loss, recon_error, perplexity) as 0-dim device tensors -- no host sync in here."""
+    def _body(self, raw, wiener):
+        """Everything of a step that runs on the device: the part a hipGraph captures."""
         x, target = self.preprocess(raw, wiener)
         self.buffers.zero_grad()
         loss, recon_error, perplexity = self.forward_loss(x, target)
         loss.backward()
-        scale = self.buffers.sync_grads(self.group)
-        self.opt.step(scale)
+        self.buffers.sync_grads(self.group)            # the step's single collective
+        self.opt.apply()
         return loss.detach(), recon_error.detach(), perplexity.detach()
+
+    def _jitters(self):
+        from .vq_vae.modules.jitter import Jitter
+        if not self.model.training:
+            return []
+        return [m for m in self.model.modules() if isinstance(m, Jitter)]
+
+    def step(self, raw, wiener=None):
+        """Returns (loss, recon_error, perplexity) as 0-dim device tensors -- no host sync in here."""
+        if self._graph is None:
+            self.opt.prepare(self.grad_scale)
+            return self._body(raw, wiener)
+        # replay: refresh the graph's static inputs (batch, jitter columns, Adam scalars), then one launch
+        self._static_raw.copy_(raw, non_blocking=True)
+        if wiener is not None:
+            self._static_wiener.copy_(wiener, non_blocking=True)
+        for j in self._graph_jitters:
+            j.refresh()
+        self.opt.prepare(self.grad_scale)
+        self._graph.replay()
+        return self._static_out
+
+    def capture(self, raw, wiener=None, warmup=3):
+        """Capture the device side of ``step`` into one hipGraph (launch-bound inner loop: ~150 launches per
+        step).  Runs ``warmup`` real training steps first (allocator + workspaces reach steady state)."""
+        assert self._graph is None, "already captured"
+        self._static_raw = raw.clone()
+        self._static_wiener = wiener.clone() if wiener is not None else None
+        L = self._static_raw.shape[1] if self.kind == "rir" else self._static_raw.shape[2]
+        self._graph_jitters = self._jitters()
+        for j in self._graph_jitters:
+            j.pin_buffer(L, raw.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                for j in self._graph_jitters:
+                    j.refresh()
+                self.opt.prepare(self.grad_scale)
+                self._body(self._static_raw, self._static_wiener)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_out = self._body(self._static_raw, self._static_wiener)
+        self._graph = graph
+        return self

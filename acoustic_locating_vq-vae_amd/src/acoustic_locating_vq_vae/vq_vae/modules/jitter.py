@@ -17,8 +17,33 @@ class Jitter(nn.Module):
         self._probability = probability
 
     def draw(self, length, device):
+        """Device int32[length] source-index vector for this call.  If ``pin_buffer`` was used, the persistent
+        buffer is returned unchanged (the owner refreshes it between hipGraph replays)."""
+        static = self.__dict__.get("_static_src")
+        if static is not None and static.numel() == length and static.device == device:
+            return static
         src = _ops.jitter_source_index(length, self._probability)
         return torch.from_numpy(src).to(device, non_blocking=True)
+
+    def pin_buffer(self, length, device):
+        """Switch to a persistent device buffer (fixed address, as a captured graph needs) and fill it."""
+        self.__dict__["_static_src"] = torch.zeros(length, dtype=torch.int32, device=device)
+        self.refresh()
+        return self.__dict__["_static_src"]
+
+    def refresh(self):
+        """Draw a new index vector (same np.random call order) into the persistent buffer."""
+        static = self.__dict__["_static_src"]
+        src = _ops.jitter_source_index(static.numel(), self._probability)
+        static.copy_(torch.from_numpy(src), non_blocking=True)
+
+    def unpin_buffer(self):
+        self.__dict__.pop("_static_src", None)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_static_src", None)     # never pickled: reference checkpoints carry no such attribute
+        return state
 
     def forward(self, quantized):
         _ops._need_gpu(quantized, "Jitter")

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="bf16: BASELINE configs[1] (bf16 storage/MFMA, fp32 accumulate+master weights); f32: parity mode")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the secondary fp32 parity-mode measurement")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -165,7 +166,22 @@ def main():
         return {k: {"launches": v[0], "ms_per_step": 1e3 * v[1] / steps, "tflops": (v[2] / v[1] / 1e12) if v[1] > 0 else None}
                 for k, v in summ.items()}
 
-    elapsed, loss, summ = measure(args.steps, args.warmup, not args.no_kernel_timer)
+    graph = "off"
+    if not args.no_graph:
+        try:
+            trainer.capture(raw, wiener)
+            graph = "hipGraph replay"
+        except Exception as exc:                           # fall back to eager launches, and say so
+            graph = "off (capture failed: %s)" % (str(exc).splitlines()[0][:120],)
+            trainer._graph = None
+    # timed region: K steps (graph replay when captured).  HIP events cannot bracket kernels inside a replay,
+    # so the per-kernel durations behind `roofline` come from an instrumented eager pass of the same K steps
+    # on the same model/batch right after it.
+    elapsed, loss, summ = measure(args.steps, args.warmup, (not args.no_kernel_timer) and trainer._graph is None)
+    if summ is None and not args.no_kernel_timer:
+        g_saved, trainer._graph = trainer._graph, None
+        _, _, summ = measure(args.steps, 1, True)
+        trainer._graph = g_saved
 
     if rank == 0:
         gf = algorithmic_gflop_per_spectrogram(cfg, L, oc)
@@ -184,6 +200,7 @@ def main():
                        "algorithmic_gflop_per_spectrogram": gf},
             "model_tflops": value * gf / 1e3,
             "final_loss": loss,
+            "launch": graph,
         }
         if summ is not None:
             line["roofline"] = roofline(summ, args.dtype, args.steps)
@@ -191,8 +208,10 @@ def main():
     if args.dtype == "bf16" and not args.no_f32_line:
         # secondary line: the fp32 parity mode (exact-fp32 MFMA, reference layout) on the same model and batch
         _ops.set_compute_dtype("f32")
+        g_saved, trainer._graph = trainer._graph, None      # eager: the bf16 graph does not apply
         s2 = max(3, min(5, args.steps))
         e2, l2, summ2 = measure(s2, 2, not args.no_kernel_timer)
+        trainer._graph = g_saved
         _ops.set_compute_dtype(args.dtype)
         if rank == 0:
             v2 = world * B * s2 / e2

@@ -141,6 +141,11 @@ int alvq_transpose_f32(const float* x, float* y, int B, int R, int C, void* stre
 int alvq_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* Graph-replayable form: the step-dependent scalars come from device memory,
+ * scalars = {lr / (1 - beta1^step), sqrt(1 - beta2^step), grad_scale}. */
+int alvq_adam_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const float* scalars, float beta1, float beta2, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * STFT power spectrogram (scripts/genereate_dataset.py:90-91,37,39,47-49; torchaudio Spectrogram semantics:
  * center=True reflect pad, periodic Hann(n_fft), one-sided, window-normalised, |.|^2).
