@@ -17,6 +17,8 @@
 // staging is LDS-DMA (global_load_lds_dwordx4, 1 KB per wave-instruction) into a lane-linear image whose 16-B
 // slots are XOR-swizzled by (row & 7) on the SOURCE address, which makes every ds_read_b128 fragment read
 // conflict-free.  Double-buffered (66 KB) -> two workgroups per CU.
+#include <stdlib.h>
+
 #include "alvq_common.h"
 #include "wgrad_reduce.h"
 
@@ -75,7 +77,7 @@ struct ConvBArgs {
   int rtiles, mtiles;
 };
 
-template <int KW, int OUT>
+template <int KW, int OUT, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
   constexpr int PAD = (KW - 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
       ntap = 0;
       nchunk = chunk + 1;
     }
-    if (step + 1 < nsteps) {
+    if (step + 1 < nsteps && DBG != 1) {
       stage_w((step + 1) & 1, ntap, nchunk);
       if (ntap == 0) stage_x(nchunk & 1, nchunk);
     }
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (DBG != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DBG != 2) __syncthreads(); else __builtin_amdgcn_s_barrier();
     tap = ntap;
     chunk = nchunk;
   }
@@ -567,6 +569,18 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
     attr = true;
   }
   const dim3 grid(a.rtiles * a.mtiles), block(256);
+  static int dbg = -1;
+  if (dbg < 0) dbg = getenv("ALVQ_DBG") ? atoi(getenv("ALVQ_DBG")) : 0;
+  if (dbg == 1 && KW == 3 && y) {
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL((conv1d_bf16_kernel<3, 0, 1>), grid, block, LDS_BYTES, s, a);
+    return check_launch("alvq_conv1d_bf16");
+  }
+  if (dbg == 2 && KW == 3 && y) {
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL((conv1d_bf16_kernel<3, 0, 2>), grid, block, LDS_BYTES, s, a);
+    return check_launch("alvq_conv1d_bf16");
+  }
   if (KW == 3) {
     if (y) hipLaunchKernelGGL((conv1d_bf16_kernel<3, 0>), grid, block, LDS_BYTES, s, a);
     else hipLaunchKernelGGL((conv1d_bf16_kernel<3, 1>), grid, block, LDS_BYTES, s, a);
