@@ -1,0 +1,106 @@
+// Shared pieces of the bf16 path: bf16<->f32 helpers, LDS-DMA wrapper, the NLC-padded layout rules and the
+// argument block of the convolution kernels.
+#pragma once
+#include "alvq_common.h"
+
+namespace alvq {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TB_R = 128;      // rows (positions) per workgroup
+constexpr int TB_M = 128;      // output channels per workgroup
+constexpr int TB_K = 64;       // channels per chunk (128-byte LDS rows)
+constexpr int XROWS = TB_R + 8;
+constexpr int XBYTES = XROWS * 128;   // 17408
+constexpr int WBYTES = TB_M * 128;    // 16384
+constexpr int CS = TB_M + 4;          // fp32 C-tile row stride (floats)
+constexpr int LDS_BYTES = 2 * XBYTES + 2 * WBYTES;  // 67584 == TB_R * CS * 4
+static_assert(LDS_BYTES >= TB_R * CS * 4, "C tile must fit");
+constexpr int GUARD_ROWS = 8;
+
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even; NaN stays NaN
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+  return (u16)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_dst, 16, 0, 0);
+}
+
+// row validity in the padded matrix: data rows are 1 + b*(L+1) + l with l < L
+__device__ __forceinline__ bool row_valid(int row, int Lp1, int nrows_data, int* b, int* l) {
+  const int v = row - 1;
+  const int bb = v / Lp1, ll = v - bb * Lp1;
+  *b = bb;
+  *l = ll;
+  return row >= 1 && v < nrows_data && ll < Lp1 - 1;
+}
+
+struct ConvBArgs {
+  const u16* x;     // [rows][Cp], points at row 0
+  const u16* wp;    // [KW][Mp128][Cp]
+  const float* bias;
+  const u16* skip1;
+  const u16* skip2;
+  const u16* mask;
+  const u16* post;
+  u16* y;
+  u16* y2;
+  float* y_ncl;     // OUT==1: (B, M, L) fp32
+  int B, L, Cp, M, Mop, Mp128;   // Mop: output row stride (M rounded to 64); Mp128: packed-weight rows per tap
+  int relu;
+  int rtiles, mtiles;
+};
+
+constexpr int WP_ROWS = 256;   // packed weights are padded to this many rows per tap (largest m-tile)
+constexpr int NLC_ROW_PAD = 256;   // activation matrices are padded to this many rows (largest row tile)
+
+// Fused epilogue for 8 consecutive output channels of one row (both conv kernels): v = acc (+bias) (+skip1)
+// (+skip2); relu; mask; y = bf16(v); y2 = bf16(v + post).  Gap / tail rows are written as zeros.
+__device__ __forceinline__ void epilogue_store8(const ConvBArgs& a, float (&v)[8], const float (&bv)[8], bool ok, long o) {
+  u16x8 out = {0, 0, 0, 0, 0, 0, 0, 0}, out2 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ok) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bv[e];
+    if (a.skip1) {
+      const u16x8 s = *(const u16x8*)(a.skip1 + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(s[e]);
+    }
+    if (a.skip2) {
+      const u16x8 s = *(const u16x8*)(a.skip2 + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(s[e]);
+    }
+    if (a.relu & 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (a.mask) {
+      const u16x8 s = *(const u16x8*)(a.mask + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = f2bf(v[e]);
+    if (a.y2) {
+      const u16x8 s = *(const u16x8*)(a.post + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out2[e] = f2bf(v[e] + bf2f(s[e]));
+    }
+  }
+  *(u16x8*)(a.y + o) = out;
+  if (a.y2) *(u16x8*)(a.y2 + o) = out2;
+}
+
+// defined in conv1d_bf16_v2.hip: the 256x256-tile kernel for wide layers
+int conv1d_bf16_v2_launch(const ConvBArgs& a, int KW, hipStream_t stream);
+
+
+}  // namespace alvq

@@ -20,62 +20,10 @@
 #include <stdlib.h>
 
 #include "alvq_common.h"
+#include "bf16_common.h"
 #include "wgrad_reduce.h"
 
 namespace alvq {
-
-typedef __bf16 bf16;
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned short u16;
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int TB_R = 128;      // rows (positions) per workgroup
-constexpr int TB_M = 128;      // output channels per workgroup
-constexpr int TB_K = 64;       // channels per chunk (128-byte LDS rows)
-constexpr int XROWS = TB_R + 8;
-constexpr int XBYTES = XROWS * 128;   // 17408
-constexpr int WBYTES = TB_M * 128;    // 16384
-constexpr int CS = TB_M + 4;          // fp32 C-tile row stride (floats)
-constexpr int LDS_BYTES = 2 * XBYTES + 2 * WBYTES;  // 67584 == TB_R * CS * 4
-static_assert(LDS_BYTES >= TB_R * CS * 4, "C tile must fit");
-constexpr int GUARD_ROWS = 8;
-
-__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even; NaN stays NaN
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
-  return (u16)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
-                                   (void __attribute__((address_space(3)))*)lds_dst, 16, 0, 0);
-}
-
-// row validity in the padded matrix: data rows are 1 + b*(L+1) + l with l < L
-__device__ __forceinline__ bool row_valid(int row, int Lp1, int nrows_data, int* b, int* l) {
-  const int v = row - 1;
-  const int bb = v / Lp1, ll = v - bb * Lp1;
-  *b = bb;
-  *l = ll;
-  return row >= 1 && v < nrows_data && ll < Lp1 - 1;
-}
-
-struct ConvBArgs {
-  const u16* x;     // [rows][Cp], points at row 0
-  const u16* wp;    // [KW][Mp128][Cp]
-  const float* bias;
-  const u16* skip1;
-  const u16* skip2;
-  const u16* mask;
-  const u16* post;
-  u16* y;
-  u16* y2;
-  float* y_ncl;     // OUT==1: (B, M, L) fp32
-  int B, L, Cp, M, Mop, Mp128;   // Mop: output row stride (M rounded to 64)
-  int relu;
-  int rtiles, mtiles;
-};
 
 template <int KW, int OUT, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
@@ -90,8 +38,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
 
   const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int m0 = (tile / a.rtiles) * TB_M;
-  const int r0 = (tile % a.rtiles) * TB_R;
+  const int m0 = (a.relu & 2 ? tile / a.rtiles : tile % a.mtiles) * TB_M;
+  const int r0 = (a.relu & 2 ? tile % a.rtiles : tile / a.mtiles) * TB_R;
   const int Cp = a.Cp;
 
   // ---- staging: lane i of a piece writes LDS row (i>>3), 16-B slot (i&7); it fetches source chunk slot^(row&7)
@@ -194,44 +142,14 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
         int b, l;
         const bool ok = row_valid(row, Lp1, ndata, &b, &l);
         const long o = (long)row * a.Mop + mbase;
-        u16x8 out = {0, 0, 0, 0, 0, 0, 0, 0}, out2 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) {
-          float v[8];
-          const f32x4 c0 = *(const f32x4*)(Cs + rl * CS + tx * 8), c1 = *(const f32x4*)(Cs + rl * CS + tx * 8 + 4);
+        float v[8];
+        const f32x4 c0 = *(const f32x4*)(Cs + rl * CS + tx * 8), c1 = *(const f32x4*)(Cs + rl * CS + tx * 8 + 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = c0[e] + bv[e];
-            v[e + 4] = c1[e] + bv[e + 4];
-          }
-          if (a.skip1) {
-            const u16x8 s = *(const u16x8*)(a.skip1 + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(s[e]);
-          }
-          if (a.skip2) {
-            const u16x8 s = *(const u16x8*)(a.skip2 + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(s[e]);
-          }
-          if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (a.mask) {
-            const u16x8 s = *(const u16x8*)(a.mask + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) out[e] = f2bf(v[e]);
-          if (a.y2) {
-            const u16x8 s = *(const u16x8*)(a.post + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) out2[e] = f2bf(v[e] + bf2f(s[e]));
-          }
+        for (int e = 0; e < 4; ++e) {
+          v[e] = c0[e];
+          v[e + 4] = c1[e];
         }
-        *(u16x8*)(a.y + o) = out;
-        if (a.y2) *(u16x8*)(a.y2 + o) = out2;
+        epilogue_store8(a, v, bv, ok, o);
       }
     }
   } else {
@@ -496,13 +414,13 @@ using namespace alvq;
 
 static inline int pad_to(int x, int q) { return (x + q - 1) / q * q; }
 
-extern "C" int64_t alvq_nlc_rows(int B, int L) { return (B <= 0 || L <= 0) ? -1 : (int64_t)pad_to(1 + B * (L + 1), TB_R); }
+extern "C" int64_t alvq_nlc_rows(int B, int L) { return (B <= 0 || L <= 0) ? -1 : (int64_t)pad_to(1 + B * (L + 1), NLC_ROW_PAD); }
 extern "C" int alvq_nlc_channels(int C) { return C <= 0 ? -1 : pad_to(C, TB_K); }
 extern "C" int alvq_nlc_guard_rows(void) { return GUARD_ROWS; }
 
 extern "C" int64_t alvq_packed_weight_elems(int M, int C, int KW) {
   if (M <= 0 || C <= 0 || (KW != 1 && KW != 3)) return -1;
-  return (int64_t)KW * pad_to(M, TB_M) * pad_to(C, TB_K);
+  return (int64_t)KW * pad_to(M, WP_ROWS) * pad_to(C, TB_K);
 }
 
 extern "C" int alvq_pack_weight_bf16(const float* w, void* wp, int M, int C, int KW, int w_layout, void* stream) {
@@ -513,7 +431,7 @@ extern "C" int alvq_pack_weight_bf16(const float* w, void* wp, int M, int C, int
   int grid = (int)((total + 1023) / 1024);
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (u16*)wp, M, C, KW,
-                     pad_to(M, TB_M), pad_to(C, TB_K), w_layout);
+                     pad_to(M, WP_ROWS), pad_to(C, TB_K), w_layout);
   return check_launch("alvq_pack_weight_bf16");
 }
 
@@ -557,9 +475,17 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
                "alvq_conv1d_bf16: the NCL fp32 epilogue fuses bias only");
   ALVQ_REQUIRE((long)B * (L + 1) < (1L << 30), ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16: problem too large");
   ConvBArgs a{(const u16*)x, (const u16*)wp, bias, (const u16*)skip1, (const u16*)skip2, (const u16*)mask, (const u16*)post,
-              (u16*)y, (u16*)y2, y_ncl, B, L, pad_to(C, TB_K), M, pad_to(M, TB_K), pad_to(M, TB_M), relu,
+              (u16*)y, (u16*)y2, y_ncl, B, L, pad_to(C, TB_K), M, pad_to(M, TB_K), pad_to(M, WP_ROWS), relu,
               (int)(alvq_nlc_rows(B, L) / TB_R), pad_to(M, TB_M) / TB_M};
   hipStream_t s = (hipStream_t)stream;
+  static int mmajor = -1;
+  if (mmajor < 0) mmajor = getenv("ALVQ_MMAJOR") ? atoi(getenv("ALVQ_MMAJOR")) : 0;
+  a.relu = (relu ? 1 : 0) | (mmajor ? 2 : 0);   // bit 1: experiment switch for the tile order
+  static int use_v2 = -1;
+  if (use_v2 < 0) use_v2 = getenv("ALVQ_CONV_V2") ? atoi(getenv("ALVQ_CONV_V2")) : 1;
+  // wide layers: 256x256 tiles (v2) whenever the 256-wide m-tile is (nearly) full; narrow or ragged M
+  // (128, 192, 201, 64, 1) stays on 128x128 tiles, which waste less there and give more workgroups.
+  if (use_v2 && pad_to(M, 256) - M <= 32) return conv1d_bf16_v2_launch(a, KW, s);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

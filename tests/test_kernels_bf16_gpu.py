@@ -35,7 +35,7 @@ def test_layout_roundtrip_and_zero_padding():
     torch.manual_seed(0)
     x = torch.randn(3, 201, 37)
     n = N.ncl_to_nlc(x.cuda())
-    assert n.Cp == 256 and n.rows == 128 and n.guard == 8
+    assert n.Cp == 256 and n.rows == 256 and n.guard == 8
     assert torch.equal(n.to_ncl().cpu(), bf(x))
     m = n.matrix().float().cpu()
     assert float(m[0].abs().sum()) == 0 and float(m[38].abs().sum()) == 0           # row 0 and the gap after sample 0
