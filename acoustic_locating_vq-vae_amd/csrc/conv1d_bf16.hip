@@ -522,7 +522,9 @@ extern "C" int64_t alvq_conv1d_wgrad_bf16_workspace_bytes(int B, int C, int M, i
   int cps;
   const int rows = (int)alvq_nlc_rows(B, L);
   const int splits = wgrad_b_splits(rows, M, C, &cps);
-  const int64_t w = (int64_t)splits * KW * M * C * 4;
+  int64_t w = (int64_t)splits * KW * M * C * 4;
+  const int64_t w2 = conv1d_wgrad_bf16_v2_workspace_bytes(rows, C, M, KW);
+  if (w2 > w) w = w2;
   const int64_t bsz = (int64_t)64 * pad_to(M, TB_K) * 4;
   return w + bsz;
 }
@@ -537,6 +539,25 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
   const int rows = (int)alvq_nlc_rows(B, L);
   int cps;
   const int splits = wgrad_b_splits(rows, M, C, &cps);
+  static int use_v2 = -1;
+  if (use_v2 < 0) use_v2 = getenv("ALVQ_WGRAD_V2") ? atoi(getenv("ALVQ_WGRAD_V2")) : 1;
+  // the bias partials live behind the LARGER of the two kernels' weight slabs
+  int64_t wbytes = (int64_t)splits * KW * M * C * 4;
+  const int64_t w2 = conv1d_wgrad_bf16_v2_workspace_bytes(rows, C, M, KW);
+  if (w2 > wbytes) wbytes = w2;
+  if (use_v2) {
+    int rc = conv1d_wgrad_bf16_v2_launch(dy, x, dw, workspace, rows, C, M, KW, w_layout, accumulate, s);
+    if (rc) return rc;
+    if (dbias) {
+      float* bpart = (float*)((char*)workspace + wbytes);
+      const int Mp = pad_to(M, TB_K), bs = 64, rps = (rows + bs - 1) / bs;
+      hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3(Mp / 64, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
+      hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
+                         accumulate);
+      rc = check_launch("alvq_conv1d_wgrad_bf16/bias");
+    }
+    return rc;
+  }
   WgradBArgs a{(const u16*)dy, (const u16*)x, (float*)workspace, pad_to(M, TB_K), pad_to(C, TB_K), M, C,
                (M + WG_M - 1) / WG_M, (C + WG_C - 1) / WG_C, splits, cps, rows};
   const int grid = a.mtiles * a.ctiles * splits;
@@ -552,7 +573,7 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
   rc = check_launch("alvq_conv1d_wgrad_bf16/reduce");
   if (rc) return rc;
   if (dbias) {
-    float* bpart = (float*)((char*)workspace + (int64_t)splits * KW * M * C * 4);
+    float* bpart = (float*)((char*)workspace + wbytes);
     const int Mp = pad_to(M, TB_K), bs = 64, rps = (rows + bs - 1) / bs;
     hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3(Mp / 64, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
     hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,

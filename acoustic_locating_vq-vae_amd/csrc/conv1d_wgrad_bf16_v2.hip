@@ -1,0 +1,295 @@
+// bf16 weight-gradient, ring-pipelined kernel (v2).
+//
+//   dW_t[m][c] = sum_rows dY[row][m] * X[row + t - pad][c]        (all taps t of one (m, c) tile per workgroup)
+//
+// The contraction runs over ROWS, the slow axis of both NLC operands, so both MFMA operands are fetched with the
+// transposing LDS read ds_read_b64_tr_b16 (two per 16x32 fragment).  Workgroup = 8 waves (2 along m x 4 along c);
+// a wave owns 64 m x (NCF*16) c for every tap: KW=3 -> NCF=2 (c-tile 128, 96 accumulator VGPRs),
+// KW=1 -> NCF=4 (c-tile 256, 64 accumulator VGPRs).  K-tile = 32 rows: a dY slab [32][128 m] (8 KB) and an X slab
+// [32 + halo][c-tile] staged ONCE and re-read at row offsets 0/1/2 by the taps.  Same 4-stage LDS-DMA ring and
+// counted-vmcnt / one-barrier-per-K-tile pipeline as conv1d_bf16_v2.hip.
+//
+// Bank conflicts: LDS rows are 256 B (or 512 B) = whole bank lines, so without care the 8 rows a half-wave reads
+// would hit the same banks.  The 32-B segment s of row r is stored at segment s ^ (r & 7) of its 256-B line
+// (swizzle applied on the DMA source address and on the read address).  The MFMA k index is also permuted --
+// lane group g takes rows {4g..4g+3} and {16+4g..16+4g+3} of the K-tile, identically for both operands, which a
+// contraction does not care about -- so each half-wave reads 8 CONSECUTIVE rows: 8 distinct segments, conflict free
+// for every tap offset.
+#include "alvq_common.h"
+#include "bf16_common.h"
+#include "wgrad_reduce.h"
+
+namespace alvq {
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+struct WgradV2Args {
+  const u16* dy;   // [rows][Mp]
+  const u16* x;    // [rows][Cp]
+  float* partial;  // [splits][KW][M][C]
+  int Mp, Cp, M, C;
+  int mtiles, ctiles, splits, chunks_per_split, total_rows;
+};
+
+// Two transposing reads (rows r..r+3 and r+16..r+19 of one 16-column block) -> one 8-element k fragment.
+// Inline asm on purpose: with the builtin, hipcc (ROCm 7.2) drains the LDS-DMA ring with s_waitcnt vmcnt(0) in
+// front of every fragment read (an in-flight LDS-DMA is a pending LDS write on the VM counter).  The reads are
+// therefore invisible to the compiler's lgkmcnt bookkeeping: the caller waits with lgkm_drain() before first use.
+typedef unsigned long long u64;
+template <int ROW_BYTES>
+__device__ __forceinline__ void tr_pair_issue(unsigned lds_addr, u64& lo, u64& hi) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(lds_addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds_addr), "n"(16 * ROW_BYTES));
+}
+__device__ __forceinline__ bf16x8_t tr_pair_join(u64 lo, u64 hi) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 v = {lo, hi};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ void lgkm_drain() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);   // keep the consuming MFMAs behind the wait (guide 5.4 rule 18)
+}
+
+template <int KW, int NCF>
+__global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Args a) {
+  constexpr int PAD = (KW - 1) / 2;
+  constexpr int MT = 128, CT = 4 * NCF * 16;          // tile: 128 m x CT c
+  constexpr int YRB = MT * 2;                          // 256 B rows
+  constexpr int XRB = CT * 2;                          // 256 or 512 B rows
+  constexpr int XROWS = KW == 1 ? 32 : 36;             // halo rows, rounded so the slab is whole 1-KB pieces
+  constexpr int YBYTES = 32 * YRB;                     // 8192
+  constexpr int XBYTES = XROWS * XRB;                  // 9216 / 16384
+  constexpr int STAGE = YBYTES + XBYTES;
+  constexpr int XPIECES = XBYTES / 1024;               // 9 / 16
+  constexpr int XROWS_PER_PIECE = 1024 / XRB;          // 4 / 2
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 64, wc0 = (wave & 3) * NCF * 16;
+
+  const int ntile = a.mtiles * a.ctiles;
+  const int id = xcd_remap(blockIdx.x, ntile * a.splits);
+  const int split = id / ntile, t_id = id % ntile;
+  const int m0 = (t_id / a.ctiles) * MT, c0 = (t_id % a.ctiles) * CT;
+  const int rbeg = split * a.chunks_per_split * 64;
+  const int rend = min(a.total_rows, rbeg + a.chunks_per_split * 64);
+  const int n = (rend - rbeg) / 32;                    // K-tiles in this split (even; may be 0)
+
+  // ---- DMA: lane i of a 1-KB piece covers bytes [16i, 16i+16): row = 16i / RB, 16-B slot = (16i % RB) / 16.
+  // The slot holds logical slot (line, ((slot>>1)&7) ^ (row&7), slot&1).
+  const int y_r = lane >> 4, y_s = lane & 15;                        // dY piece: 4 rows x 16 slots
+  const int x_r = (lane * 16) / XRB, x_s = ((lane * 16) % XRB) >> 4;  // X piece: 4 x 16 or 2 x 32 slots
+  auto src_slot = [](int slot, int row) { return (slot & 16) | (((((slot >> 1) & 7) ^ (row & 7)) << 1) | (slot & 1)); };
+  const int last_row = a.total_rows - 1;
+
+  int is_row = rbeg;   // first row of the K-tile the next issue() stages
+  auto issue = [&](int stage) {
+    unsigned char* dst = lds + stage * STAGE;
+    {  // dY: piece = wave (rows 4*wave .. +3)
+      const int lr = 4 * wave + y_r;
+      const int mcol = min(m0 + src_slot(y_s, lr) * 8, a.Mp - 8);   // tiles past Mp re-read the last chunk (discarded)
+      glds16(a.dy + (long)(is_row + lr) * a.Mp + mcol, dst + wave * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < (XPIECES + 7) / 8; ++q) {
+      const int p = wave + 8 * q;
+      if (p < XPIECES) {
+        const int lr = p * XROWS_PER_PIECE + x_r;
+        int gr = is_row - PAD + lr;                                  // rows outside the matrix -> a zero row
+        gr = gr < 0 ? 0 : (gr > last_row ? last_row : gr);
+        const int ccol = min(c0 + src_slot(x_s, lr) * 8, a.Cp - 8);
+        glds16(a.x + (long)gr * a.Cp + ccol, dst + YBYTES + p * 1024);
+      }
+    }
+    is_row += 32;
+  };
+  // glds issued per K-tile by THIS wave (for the counted waits)
+  const bool extra = (XPIECES % 8 != 0) && (wave < XPIECES % 8);
+
+  // ---- transposed fragment reads.  Lane (g = lane>>4, q = (lane>>2)&3, p = lane&3) supplies the address of block
+  // row q, columns 4p..4p+3; block rows of group g: 4g + q (first read) and 16 + 4g + q (second read).
+  const int g = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int krow = 4 * g + q4;
+  int ybase, xbase[KW];
+  ybase = krow * YRB + ((krow & 7) << 5) + p4 * 8;
+#pragma unroll
+  for (int t = 0; t < KW; ++t) xbase[t] = (krow + t) * XRB + (((krow + t) & 7) << 5) + p4 * 8;
+  // column-block terms (wave-uniform): block index cb -> line = cb >> 3, segment = cb & 7
+  int yseg[4], xseg[NCF], xline[NCF];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) yseg[mi] = ((wm0 >> 4) + mi) << 5;          // MT = 128 -> 8 blocks, one line
+#pragma unroll
+  for (int cf = 0; cf < NCF; ++cf) {
+    const int cb = (wc0 >> 4) + cf;
+    xseg[cf] = (cb & 7) << 5;
+    xline[cf] = (cb >> 3) * 256;
+  }
+
+  struct Raw {       // fragment halves as they come back from the transposing reads
+    u64 alo[4], ahi[4];
+    u64 blo[KW][NCF], bhi[KW][NCF];
+  };
+  struct Frags {
+    bf16x8_t a[4];
+    bf16x8_t b[KW][NCF];
+  };
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds;
+  auto rd = [&](Raw& f, int stage) {
+    const unsigned ys = lds0 + stage * STAGE;
+    const unsigned xs = ys + YBYTES;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) tr_pair_issue<YRB>(ys + (ybase ^ yseg[mi]), f.alo[mi], f.ahi[mi]);
+#pragma unroll
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf)
+        tr_pair_issue<XRB>(xs + ((xbase[t] ^ xseg[cf]) + xline[cf]), f.blo[t][cf], f.bhi[t][cf]);
+  };
+  auto join = [&](Frags& f, const Raw& r) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) f.a[mi] = tr_pair_join(r.alo[mi], r.ahi[mi]);
+#pragma unroll
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf) f.b[t][cf] = tr_pair_join(r.blo[t][cf], r.bhi[t][cf]);
+  };
+
+  f32x4 acc[KW][4][NCF];
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NCF; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mm = [&](const Frags& f, int half) {
+#pragma unroll
+    for (int mi = half * 2; mi < half * 2 + 2; ++mi)
+#pragma unroll
+      for (int t = 0; t < KW; ++t)
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf)
+          acc[t][mi][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[mi], f.b[t][cf], acc[t][mi][cf], 0, 0, 0);
+  };
+  auto wait_keep = [&](int tiles_in_flight) {   // leave the DMA of `tiles_in_flight` K-tiles (0..2) outstanding
+    if (tiles_in_flight == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (XPIECES % 8 == 0) {
+      if (tiles_in_flight == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (extra) {
+      if (tiles_in_flight == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      if (tiles_in_flight == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+  };
+
+  Raw r0, r1;
+  Frags f0, f1;
+  if (n > 0) {
+    issue(0);
+    issue(1);
+    if (n > 2) issue(2);
+    wait_keep(n > 2 ? 2 : 1);
+    __builtin_amdgcn_s_barrier();
+    rd(r0, 0);
+    wait_keep(n > 2 ? 1 : 0);
+    lgkm_drain();
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < n; t += 2) {
+      // ---- even K-tile t (its reads sit in r0, complete)
+      join(f0, r0);
+      if (t + 3 < n) issue((t + 3) & 3);
+      mm(f0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(r1, (t + 1) & 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(f0, 1);
+      wait_keep(t + 3 < n ? 1 : 0);
+      lgkm_drain();                        // r1 landed (issued 12+ MFMAs ago)
+      __builtin_amdgcn_s_barrier();
+      // ---- odd K-tile t+1
+      join(f1, r1);
+      if (t + 4 < n) issue((t + 4) & 3);
+      mm(f1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < n) rd(r0, (t + 2) & 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(f1, 1);
+      wait_keep(t + 4 < n ? 1 : 0);
+      lgkm_drain();
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- partial[split][t][m][c] = acc (fp32); D[i = m][j = c]
+  const int li = lane & 15, kq = lane >> 4;
+  float* out = a.partial + (long)split * KW * a.M * a.C;
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm0 + mi * 16 + kq * 4 + r;
+          const int c = c0 + wc0 + cf * 16 + li;
+          if (m < a.M && c < a.C) out[((long)t * a.M + m) * a.C + c] = acc[t][mi][cf][r];
+        }
+}
+
+template <int KW, int NCF>
+static constexpr int wgrad_v2_lds() {
+  return 4 * (32 * 256 + (KW == 1 ? 32 : 36) * (4 * NCF * 16 * 2));
+}
+
+static int wgrad_v2_splits(int total_rows, int tiles, int* chunks_per_split) {
+  const int nchunks = total_rows / 64;
+  int want = (256 + tiles - 1) / tiles;   // one workgroup per CU
+  if (want < 1) want = 1;
+  if (want > nchunks) want = nchunks;
+  if (want > 64) want = 64;
+  const int cps = (nchunks + want - 1) / want;
+  *chunks_per_split = cps;
+  return (nchunks + cps - 1) / cps;
+}
+
+int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int KW) {
+  const int ct = KW == 3 ? 128 : 256;
+  const int tiles = ((M + 127) / 128) * ((C + ct - 1) / ct);
+  int cps;
+  const int splits = wgrad_v2_splits(total_rows, tiles, &cps);
+  return (int64_t)splits * KW * M * C * 4;
+}
+
+int conv1d_wgrad_bf16_v2_launch(const void* dy, const void* x, float* dw, void* workspace, int total_rows, int C, int M,
+                                int KW, int w_layout, int accumulate, hipStream_t s) {
+  const int ct = KW == 3 ? 128 : 256;
+  const int Mp = (M + 63) / 64 * 64, Cp = (C + 63) / 64 * 64;
+  WgradV2Args a{(const u16*)dy, (const u16*)x, (float*)workspace, Mp, Cp, M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, total_rows};
+  a.splits = wgrad_v2_splits(total_rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<3, 2>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<1, 4>());
+    attr = true;
+  }
+  const int grid = a.mtiles * a.ctiles * a.splits;
+  if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<3, 2>), dim3(grid), dim3(512), (wgrad_v2_lds<3, 2>()), s, a);
+  else hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<1, 4>), dim3(grid), dim3(512), (wgrad_v2_lds<1, 4>()), s, a);
+  int rc = check_launch("alvq_conv1d_wgrad_bf16(v2)");
+  if (rc) return rc;
+  const long total = (long)KW * M * C;
+  int rgrid = (int)((total + 255) / 256);
+  if (rgrid > 2048) rgrid = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, a.splits, KW, M, C, w_layout,
+                     accumulate);
+  return check_launch("alvq_conv1d_wgrad_bf16(v2)/reduce");
+}
+
+}  // namespace alvq
