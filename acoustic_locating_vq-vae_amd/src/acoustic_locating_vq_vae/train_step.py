@@ -168,14 +168,18 @@ class Trainer:
         return recon_error + vq_loss, recon_error, perplexity
 
     def _body(self, raw, wiener):
-        """Everything of a step that runs on the device: the part a hipGraph captures."""
+        """Preprocess + forward + backward: the launch-bound part of a step (~150 launches) that a hipGraph
+        captures.  The collective and the optimiser launch stay outside (``_finish``) so no RCCL call is ever
+        recorded into a graph."""
         x, target = self.preprocess(raw, wiener)
         self.buffers.zero_grad()
         loss, recon_error, perplexity = self.forward_loss(x, target)
         loss.backward()
-        self.buffers.sync_grads(self.group)            # the step's single collective
-        self.opt.apply()
         return loss.detach(), recon_error.detach(), perplexity.detach()
+
+    def _finish(self):
+        self.buffers.sync_grads(self.group)            # the step's single collective (eager, on the same stream)
+        self.opt.apply()                               # one Adam launch over the flat buffer
 
     def _jitters(self):
         from .vq_vae.modules.jitter import Jitter
@@ -187,7 +191,9 @@ class Trainer:
         """Returns (loss, recon_error, perplexity) as 0-dim device tensors -- no host sync in here."""
         if self._graph is None:
             self.opt.prepare(self.grad_scale)
-            return self._body(raw, wiener)
+            out = self._body(raw, wiener)
+            self._finish()
+            return out
         # replay: refresh the graph's static inputs (batch, jitter columns, Adam scalars), then one launch
         self._static_raw.copy_(raw, non_blocking=True)
         if wiener is not None:
@@ -196,10 +202,11 @@ class Trainer:
             j.refresh()
         self.opt.prepare(self.grad_scale)
         self._graph.replay()
+        self._finish()
         return self._static_out
 
     def capture(self, raw, wiener=None, warmup=3):
-        """Capture the device side of ``step`` into one hipGraph (launch-bound inner loop: ~150 launches per
+        """Capture preprocess + forward + backward into one hipGraph (launch-bound inner loop: ~150 launches per
         step).  Runs ``warmup`` real training steps first (allocator + workspaces reach steady state)."""
         assert self._graph is None, "already captured"
         self._static_raw = raw.clone()
@@ -216,6 +223,7 @@ class Trainer:
                     j.refresh()
                 self.opt.prepare(self.grad_scale)
                 self._body(self._static_raw, self._static_wiener)
+                self._finish()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()

@@ -26,9 +26,10 @@ class Jitter(nn.Module):
         return torch.from_numpy(src).to(device, non_blocking=True)
 
     def pin_buffer(self, length, device):
-        """Switch to a persistent device buffer (fixed address, as a captured graph needs) and fill it."""
-        self.__dict__["_static_src"] = torch.zeros(length, dtype=torch.int32, device=device)
-        self.refresh()
+        """Switch to a persistent device buffer (fixed address, as a captured graph needs).  It starts as the
+        identity (no column replaced) and draws nothing, so the np.random stream stays aligned with an eager run;
+        the owner calls ``refresh()`` before every step."""
+        self.__dict__["_static_src"] = torch.arange(length, dtype=torch.int32, device=device)
         return self.__dict__["_static_src"]
 
     def refresh(self):
