@@ -362,18 +362,35 @@ __global__ __launch_bounds__(256) void nlc_to_ncl_kernel(const u16* x, float* y,
   }
 }
 
-// column sums of an NLC matrix: partial[s][m] = sum over the split's rows of dy[row][m]
+// column sums of an NLC matrix: partial[s][m] = sum over the split's rows of dy[row][m].
+// Thread = 8 consecutive channels (one 16-B load per row, rows fully coalesced); grid = (channel groups, splits).
 __global__ __launch_bounds__(256) void bias_grad_nlc_partial_kernel(const u16* dy, float* partial, int rows, int Mp,
                                                                     int rows_per_split) {
-  const int m = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+  const int groups = Mp / 8;                         // 16-B channel groups per row
+  const int gpb = groups < 256 ? groups : 256;       // groups handled by this block (threads along channels)
+  const int rsub = 256 / gpb;                        // row phases inside the block
+  const int gi = threadIdx.x % gpb, rp = threadIdx.x / gpb;
+  const int grp = blockIdx.x * gpb + gi;
   const int rb = blockIdx.y * rows_per_split, re = min(rows, rb + rows_per_split);
-  float s = 0.f;
-  if (m < Mp)
-    for (int r = rb + sub; r < re; r += 4) s += bf2f(dy[(long)r * Mp + m]);
-  __shared__ float red[4][64];
-  red[sub][threadIdx.x & 63] = s;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (grp < groups && rp < rsub)
+    for (int r = rb + rp; r < re; r += rsub) {
+      const u16x8 v = *(const u16x8*)(dy + (long)r * Mp + grp * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += bf2f(v[e]);
+    }
+  __shared__ float red[256][9];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
   __syncthreads();
-  if (sub == 0 && m < Mp) partial[(long)blockIdx.y * Mp + m] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rp == 0 && grp < groups) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      for (int k = 0; k < rsub; ++k) t += red[k * gpb + gi][e];
+      partial[(long)blockIdx.y * Mp + grp * 8 + e] = t;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void bias_grad_nlc_final_kernel(const float* partial, float* dbias, int splits, int Mp, int M,
@@ -551,7 +568,7 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
     if (dbias) {
       float* bpart = (float*)((char*)workspace + wbytes);
       const int Mp = pad_to(M, TB_K), bs = 64, rps = (rows + bs - 1) / bs;
-      hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3(Mp / 64, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
+      hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
       hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
                          accumulate);
       rc = check_launch("alvq_conv1d_wgrad_bf16/bias");
@@ -575,7 +592,7 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
   if (dbias) {
     float* bpart = (float*)((char*)workspace + wbytes);
     const int Mp = pad_to(M, TB_K), bs = 64, rps = (rows + bs - 1) / bs;
-    hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3(Mp / 64, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
+    hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
     hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
                        accumulate);
     rc = check_launch("alvq_conv1d_wgrad_bf16/bias");

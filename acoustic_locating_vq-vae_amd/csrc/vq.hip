@@ -237,20 +237,33 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* partials,
   }
 }
 
+constexpr int VQ_PRIV = 16;   // private copies of dE the scatter-add is spread over (hot codes serialise on one copy)
+
+// priv: VQ_PRIV x K x D zeroed floats (or NULL: add straight into dE).
 __global__ __launch_bounds__(256) void vq_backward_kernel(const float* g, const float* grad_loss, const float* x,
                                                           const float* e, const int64_t* idx, float* dx, float* dE,
-                                                          long N, int K, int D, float cx, float ce) {
+                                                          float* priv, long N, int K, int D, float cx, float ce) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float gl = grad_loss ? grad_loss[0] : 1.f;
   const float sx = gl * cx, se = gl * ce;
+  float* acc = dE ? (priv ? priv + (long)(blockIdx.x % VQ_PRIV) * K * D : dE) : nullptr;
   for (long r = (long)blockIdx.x * 4 + wave; r < N; r += (long)gridDim.x * 4) {
     const long k = idx[r];
     for (int d = lane; d < D; d += 64) {
       const float xv = x[r * D + d];
       const float diff = e[k * D + d] - xv;  // q - x
       if (dx) dx[r * D + d] = (g ? g[r * D + d] : 0.f) - sx * diff;
-      if (dE) atomicAdd(&dE[k * D + d], se * diff);
+      if (acc) atomicAdd(&acc[k * D + d], se * diff);
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void vq_priv_reduce_kernel(const float* priv, float* dE, long kd) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < kd; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < VQ_PRIV; ++p) s += priv[p * kd + i];
+    dE[i] += s;
   }
 }
 
@@ -321,14 +334,27 @@ extern "C" int alvq_vq_finalize_f32(const float* sq_partials, const int32_t* his
   return check_launch("alvq_vq_finalize_f32");
 }
 
+extern "C" int64_t alvq_vq_backward_workspace_bytes(int K, int D) {
+  return (K <= 0 || D <= 0) ? -1 : (int64_t)VQ_PRIV * K * D * (int64_t)sizeof(float);
+}
+
 extern "C" int alvq_vq_backward_f32(const float* g, const float* grad_loss, const float* x, const float* codebook,
-                                    const int64_t* idx, float* dx, float* dE, int64_t N, int K, int D, float beta,
-                                    void* stream) {
+                                    const int64_t* idx, float* dx, float* dE, void* workspace, int64_t N, int K, int D,
+                                    float beta, void* stream) {
   ALVQ_REQUIRE(x && codebook && idx && (dx || dE), ALVQ_EINVAL, "alvq_vq_backward_f32: null pointer");
   ALVQ_REQUIRE(N > 0 && K > 0 && D > 0, ALVQ_EINVAL, "alvq_vq_backward_f32: bad dims");
   const double nd = (double)N * (double)D;
-  hipLaunchKernelGGL(vq_backward_kernel, dim3(grid_for(N, 4)), dim3(256), 0, (hipStream_t)stream, g, grad_loss, x,
-                     codebook, idx, dx, dE, (long)N, K, D, (float)(2.0 * beta / nd), (float)(2.0 / nd));
+  hipStream_t s = (hipStream_t)stream;
+  float* priv = dE ? (float*)workspace : nullptr;
+  if (priv) {
+    hipError_t e = hipMemsetAsync(priv, 0, (size_t)VQ_PRIV * K * D * sizeof(float), s);
+    ALVQ_REQUIRE(e == hipSuccess, (int)e, "alvq_vq_backward_f32: memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(vq_backward_kernel, dim3(grid_for(N, 4)), dim3(256), 0, s, g, grad_loss, x, codebook, idx, dx, dE,
+                     priv, (long)N, K, D, (float)(2.0 * beta / nd), (float)(2.0 / nd));
+  if (priv)
+    hipLaunchKernelGGL(vq_priv_reduce_kernel, dim3(grid_for((long)K * D, 256)), dim3(256), 0, s, (const float*)priv, dE,
+                       (long)K * D);
   return check_launch("alvq_vq_backward_f32");
 }
 

@@ -36,7 +36,8 @@ _SIGNATURES = {
     "alvq_vq_argmin_f32": (_i32, [_c_void_p] * 5 + [_i64, _i32, _i32, _c_void_p]),
     "alvq_vq_gather_loss_f32": (_i32, [_c_void_p] * 6 + [_i64, _i32, _i32, _c_void_p]),
     "alvq_vq_finalize_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _i32, _f32, _c_void_p]),
-    "alvq_vq_backward_f32": (_i32, [_c_void_p] * 7 + [_i64, _i32, _i32, _f32, _c_void_p]),
+    "alvq_vq_backward_workspace_bytes": (_i64, [_i32, _i32]),
+    "alvq_vq_backward_f32": (_i32, [_c_void_p] * 8 + [_i64, _i32, _i32, _f32, _c_void_p]),
     "alvq_onehot_f32": (_i32, [_c_void_p, _c_void_p, _i64, _i32, _c_void_p]),
     "alvq_jitter_gather_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _i32, _c_void_p]),
     "alvq_standardise_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
@@ -261,9 +262,10 @@ def vq_backward(g, grad_loss, flat, codebook, idx, beta, want_dx=True, want_dE=T
     K = codebook.shape[0]
     dx = torch.empty_like(flat) if want_dx else None
     dE = torch.zeros_like(codebook) if want_dE else None
+    ws = _workspace(lib().alvq_vq_backward_workspace_bytes(K, D), flat.device).data_ptr() if want_dE else None
     _check(lib().alvq_vq_backward_f32(_ptr(g, name="g"), _ptr(grad_loss, name="grad_loss"), _ptr(flat, name="x"),
                                       _ptr(codebook, name="codebook"), _ptr(idx, torch.int64, "idx"), _ptr(dx), _ptr(dE),
-                                      N, K, D, float(beta), _stream()), "alvq_vq_backward_f32")
+                                      ws, N, K, D, float(beta), _stream()), "alvq_vq_backward_f32")
     return dx, dE
 
 
@@ -444,7 +446,9 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     else:
         y = nlc_like(x, M)
         y2 = nlc_like(x, M) if post is not None else None
-    with _timed("conv1d_bf16_kernel", 2.0 * x.B * x.L * M * C * KW):
+    # same dispatch rule as alvq_conv1d_bf16: wide layers run the 256x256-tile kernel
+    family = "conv1d_bf16_v2_kernel" if ((M + 255) // 256 * 256 - M) <= 32 else "conv1d_bf16_kernel"
+    with _timed(family, 2.0 * x.B * x.L * M * C * KW):
         rc = lib().alvq_conv1d_bf16(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),
                                     _nlc_ptr(skip2, x, M, "skip2"), _nlc_ptr(mask, x, M, "mask"),
                                     _nlc_ptr(post, x, M, "post"), y.ptr if y is not None else None,
@@ -469,7 +473,7 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
     if want_bias and dbias_out is None:
         dbias_out = torch.empty((M,), device=dev, dtype=torch.float32)
     ws = _workspace(lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x.B, C, M, x.L, KW), dev)
-    with _timed("conv1d_wgrad_bf16_kernel", 2.0 * x.B * x.L * M * C * KW):
+    with _timed("conv1d_wgrad_bf16_v2_kernel", 2.0 * x.B * x.L * M * C * KW):
         rc = lib().alvq_conv1d_wgrad_bf16(dy.ptr, x.ptr, _ptr(dw_out, name="dw"),
                                           _ptr(dbias_out, name="dbias") if want_bias else None, ws.data_ptr(),
                                           x.B, C, M, x.L, KW, w_layout, int(bool(accumulate)), _stream())

@@ -28,7 +28,8 @@ import torch.distributed as dist  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 matrix rate (= vector rate)
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (NOT the 2:1-sparsity headline)
 PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS}
-CONV_FAMILY = {"f32": "conv1d_f32_kernel", "bf16": "conv1d_bf16_kernel"}
+CONV_FAMILIES = {"f32": ("conv1d_f32_kernel", "conv1d_wgrad_f32_kernel"),
+                 "bf16": ("conv1d_bf16_v2_kernel", "conv1d_bf16_kernel", "conv1d_wgrad_bf16_v2_kernel")}
 SPEECH_CFG = (201, 1024, 128, 3, 1024, 0.25, 1024)          # scripts/train_speech.py:152-153
 RIR_CFG = (500, 1024, 64, 2, 64, 0.25, 1024)                # scripts/train_rir.py:147-149
 
@@ -151,7 +152,8 @@ def main():
         return dt, last, (timer.summary() if timer is not None else None)
 
     def roofline(summ, dtype, steps):
-        fam = CONV_FAMILY[dtype]
+        # the dominant kernel = the conv kernel with the largest share of the timed region
+        fam = max((f for f in CONV_FAMILIES[dtype] if f in summ), key=lambda f: summ[f][1])
         n, secs, flops = summ[fam]
         ach = flops / secs / 1e12
         traffic = None

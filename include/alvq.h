@@ -98,10 +98,14 @@ int alvq_vq_finalize_f32(const float* sq_partials, const int32_t* hist, float* o
 
 /* Backward:  dx = g + gl*(2*beta/(N*D))*(x - E[idx]);
  * dE[k] += gl*(2/(N*D)) * sum_{n: idx_n = k} (E[k] - x_n)  (skipped when dE == NULL, i.e. _train_vq False);
- * g = grad wrt q_st (may be NULL = 0), gl = *grad_loss (device scalar, may be NULL = 1). dE must be zeroed by
- * the caller (it is accumulated with float atomics). */
+ * g = grad wrt q_st (may be NULL = 0), gl = *grad_loss (device scalar, may be NULL = 1).  dE must be zeroed by the
+ * caller.  The scatter-add uses float atomics (the only ones on the path); with `workspace`
+ * (alvq_vq_backward_workspace_bytes(K,D) bytes, may be NULL) it is spread over private copies so hot codes do
+ * not serialise. */
+int64_t alvq_vq_backward_workspace_bytes(int K, int D);
 int alvq_vq_backward_f32(const float* g, const float* grad_loss, const float* x, const float* codebook,
-                         const int64_t* idx, float* dx, float* dE, int64_t N, int K, int D, float beta, void* stream);
+                         const int64_t* idx, float* dx, float* dE, void* workspace, int64_t N, int K, int D, float beta,
+                         void* stream);
 
 /* Dense one-hot encodings (N,K) fp32 (:39-40) -- only materialised for get_latent_representation callers. */
 int alvq_onehot_f32(const int64_t* idx, float* encodings, int64_t N, int K, void* stream);
