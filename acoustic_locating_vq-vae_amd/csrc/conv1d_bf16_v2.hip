@@ -37,7 +37,8 @@ struct FragSet {
   bf16x8_t b[4];
 };
 
-// DBG (timing experiments only, wrong results): 1 = no DMA in the loop, 2 = no vmcnt waits, 3 = no barriers
+// DBG (timing experiments; 1-3 give wrong results): 1 = no DMA in the loop, 2 = no vmcnt waits, 3 = no barriers,
+// 4 = no issue stagger (correct results)
 template <int OUT, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int KW) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
   };
 
   const int n = (Cp / V2_K) * KW;   // K-tiles; always even (Cp % 64 == 0)
+  constexpr bool STAGGER = (DBG != 4);
+  const bool early = wave < 4;
   FragSet f0, f1;
 
   // ---- prologue: K-tiles 0..2 in flight, fragments of K-tile 0 in f0, K-tile 1 landed
@@ -131,11 +134,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
 
   for (int t = 0; t < n; t += 2) {
     // ---- even K-tile t (fragments in f0)
-    if (t + 3 < n && DBG != 1) issue((t + 3) & 3);
+    // stagger: the older four waves issue their DMA before the MFMAs, the younger four (their SIMD partners)
+    // between the MFMA halves, so the two waves of a SIMD are not both stuck in DMA issue at the same time
+    if (t + 3 < n && DBG != 1 && (early || !STAGGER)) issue((t + 3) & 3);
     mm(f0, 0);
     __builtin_amdgcn_sched_barrier(0);   // pin: reads go BETWEEN the MFMA halves (hipcc otherwise hoists them
     rd(f1, (t + 1) & 3);                 // above all 32 MFMAs and then waits lgkmcnt(0) in front of the first one)
     __builtin_amdgcn_sched_barrier(0);
+    if (t + 3 < n && DBG != 1 && STAGGER && !early) issue((t + 3) & 3);
     mm(f0, 1);
     if (DBG != 2 && DBG != 1) {
       if (t + 3 < n) {
@@ -146,11 +152,12 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
     }
     if (DBG != 3) __builtin_amdgcn_s_barrier();
     // ---- odd K-tile t+1 (fragments in f1)
-    if (t + 4 < n && DBG != 1) issue((t + 4) & 3);
+    if (t + 4 < n && DBG != 1 && (early || !STAGGER)) issue((t + 4) & 3);
     mm(f1, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (t + 2 < n) rd(f0, (t + 2) & 3);
     __builtin_amdgcn_sched_barrier(0);
+    if (t + 4 < n && DBG != 1 && STAGGER && !early) issue((t + 4) & 3);
     mm(f1, 1);
     if (DBG != 2 && DBG != 1) {
       if (t + 4 < n) {
@@ -235,11 +242,12 @@ int conv1d_bf16_v2_launch(const ConvBArgs& a_in, int KW, hipStream_t stream) {
   static int dbg = -1;
   if (dbg < 0) dbg = getenv("ALVQ_DBG") ? atoi(getenv("ALVQ_DBG")) : 0;
   if (dbg && a.y) {
-    const void* fn = dbg == 1 ? (const void*)conv1d_bf16_v2_kernel<0, 1> : dbg == 2 ? (const void*)conv1d_bf16_v2_kernel<0, 2> : (const void*)conv1d_bf16_v2_kernel<0, 3>;
+    const void* fn = dbg == 1 ? (const void*)conv1d_bf16_v2_kernel<0, 1> : dbg == 2 ? (const void*)conv1d_bf16_v2_kernel<0, 2> : dbg == 3 ? (const void*)conv1d_bf16_v2_kernel<0, 3> : (const void*)conv1d_bf16_v2_kernel<0, 4>;
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
     if (dbg == 1) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 1>), grid, block, V2_LDS, stream, a, KW);
     else if (dbg == 2) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 2>), grid, block, V2_LDS, stream, a, KW);
-    else hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 3>), grid, block, V2_LDS, stream, a, KW);
+    else if (dbg == 3) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 3>), grid, block, V2_LDS, stream, a, KW);
+    else hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 4>), grid, block, V2_LDS, stream, a, KW);
     return check_launch("alvq_conv1d_bf16(v2 dbg)");
   }
   if (a.y) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0>), grid, block, V2_LDS, stream, a, KW);
