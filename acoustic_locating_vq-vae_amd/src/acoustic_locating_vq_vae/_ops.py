@@ -403,17 +403,41 @@ class MSEFn(torch.autograd.Function):
 
 
 def jitter_source_index(length, probability):
-    """Host side of Jitter: same ``np.random`` call order as modules/jitter.py:50-68 (one draw per column, one
-    more per replaced interior column; a column is replaced with probability 1 - p, the inversion at :55)."""
+    """Host side of Jitter: the index each output column copies from, consuming ``np.random`` exactly as
+    modules/jitter.py:50-68 does -- one draw per column (``choice([1, 0], p=[p, 1-p])``; the column is replaced when
+    the draw is 0, i.e. with probability 1 - p: the inversion at :55) and one more per replaced interior column
+    (``choice([-1, 1], p=[.5, .5])``).
+
+    ``RandomState.choice(a, p=...)`` with no size draws ONE ``random_sample()`` u and returns
+    ``a[searchsorted(cumsum(p), u, side='right')]``, so the stream is reproduced from raw uniforms: replaced iff
+    u >= p, neighbour = -1 iff u' < 0.5.  The reference's 500-iteration Python loop of ``choice`` calls costs ~9 ms
+    per step on the host -- as long as the whole GPU step -- so the uniforms are drawn in two vectorised calls:
+    a look-ahead block to learn how many the sequential rule consumes, then the state is rewound and exactly that
+    many are drawn (identical values, identical final generator state)."""
+    rng = np.random.mtrand._rand          # the global RandomState that np.random.choice uses
+    p = float(probability)
+    if length < 2:                        # no neighbour to copy from (the reference would raise IndexError)
+        rng.random_sample(length)
+        return np.arange(length, dtype=np.int32)
+    cdf0 = np.cumsum(np.array([p, 1.0 - p]))
+    cdf0 /= cdf0[-1]
+    thr = float(cdf0[0])                  # same normalisation as choice()
+    state = rng.get_state()
+    u = rng.random_sample(2 * length)     # upper bound on the draws
     src = np.arange(length, dtype=np.int32)
-    choice = np.random.choice
+    ptr = 0
+    last = length - 1
     for i in range(length):
-        replace = [True, False][choice([1, 0], p=[probability, 1 - probability])]
-        if replace:
+        replaced = u[ptr] >= thr
+        ptr += 1
+        if replaced:
             if i == 0:
                 src[i] = 1
-            elif i == length - 1:
+            elif i == last:
                 src[i] = i - 1
             else:
-                src[i] = i + choice([-1, 1], p=[0.5, 0.5])
+                src[i] = i + (-1 if u[ptr] < 0.5 else 1)
+                ptr += 1
+    rng.set_state(state)
+    rng.random_sample(ptr)                # leave the generator exactly where the reference's loop would
     return src
