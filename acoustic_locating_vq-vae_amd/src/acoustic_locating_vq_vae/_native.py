@@ -49,6 +49,7 @@ _SIGNATURES = {
     "alvq_adam_f32": (_i32, [_c_void_p] * 4 + [_i64, _i32, _f32, _f32, _f32, _f32, _f32, _c_void_p]),
     "alvq_adam_dev_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p, _f32, _f32, _f32, _c_void_p]),
     "alvq_stft_power_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_stft_power_f64": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_nlc_rows": (_i64, [_i32, _i32]),
     "alvq_nlc_channels": (_i32, [_i32]),
     "alvq_nlc_guard_rows": (_i32, []),
@@ -345,9 +346,14 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.
 
 
 def stft_power(wave, n_fft=400, hop=160):
+    """Power spectrogram of (B,S) waveforms, fp32 or fp64 (the reference's echoed signal is float64)."""
     B, S = wave.shape
-    power = torch.empty((B, n_fft // 2 + 1, 1 + S // hop), device=wave.device, dtype=torch.float32)
-    _check(lib().alvq_stft_power_f32(_ptr(wave, name="wave"), _ptr(power), B, S, n_fft, hop, _stream()), "alvq_stft_power_f32")
+    power = torch.empty((B, n_fft // 2 + 1, 1 + S // hop), device=wave.device, dtype=wave.dtype)
+    if wave.dtype == torch.float64:
+        _check(lib().alvq_stft_power_f64(_ptr(wave, torch.float64, "wave"), _ptr(power, torch.float64), B, S, n_fft, hop,
+                                         _stream()), "alvq_stft_power_f64")
+    else:
+        _check(lib().alvq_stft_power_f32(_ptr(wave, name="wave"), _ptr(power), B, S, n_fft, hop, _stream()), "alvq_stft_power_f32")
     return power
 
 

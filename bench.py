@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU")
-    ap.add_argument("--config", default="speech", choices=["speech", "rir"])
+    ap.add_argument("--config", default="speech", choices=["speech", "rir", "echoed"],
+                    help="speech = BASELINE configs[1] (the headline); rir = configs[2]; echoed = configs[4]")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="bf16: BASELINE configs[1] (bf16 storage/MFMA, fp32 accumulate+master weights); f32: parity mode")
     ap.add_argument("--no-f32-line", action="store_true", help="skip the secondary fp32 parity-mode measurement")
@@ -113,10 +114,18 @@ def main():
         cfg, L, oc = SPEECH_CFG, 500, None
         model = ConvolutionalVQVAE(*cfg).cuda()
         kind = "speech"
-    else:
+    elif args.config == "rir":
         cfg, L, oc = RIR_CFG, 201, 1
         model = ConvolutionalVQVAE(*cfg, use_jitter=False, out_channels=1).cuda()
         kind = "rir"
+    else:
+        # scripts/train_echoed_speech.py:45-46 from two freshly initialised sub-models (no checkpoints ship)
+        from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
+        cfg, L, oc = SPEECH_CFG, 500, None
+        rir = ConvolutionalVQVAE(*RIR_CFG, use_jitter=False, out_channels=1)
+        sp = ConvolutionalVQVAE(*SPEECH_CFG)
+        model = EchoedSpeechReconModel(rir, sp, 201, 1024, 2, 1024, True).cuda()
+        kind = "echoed"
     model.train()
     trainer = Trainer(model, kind)
     g = torch.Generator(device="cuda")
@@ -186,18 +195,18 @@ def main():
         trainer._graph = g_saved
 
     if rank == 0:
-        gf = algorithmic_gflop_per_spectrogram(cfg, L, oc)
+        gf = 61.73 if kind == "echoed" else algorithmic_gflop_per_spectrogram(cfg, L, oc)
         value = world * B * args.steps / elapsed
         line = {
-            "metric": "spectrograms/sec (train step), speech VQ-VAE default config",
+            "metric": "spectrograms/sec (train step), %s VQ-VAE default config" % ("echoed-speech" if kind == "echoed" else kind),
             "value": value, "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s VQ-VAE train step (fwd+bwd+Adam), ctor %s, B=%d per GPU x (%s), %s, jitter %s"
-                                   % (kind, list(cfg), B, "201,500" if kind == "speech" else "500,201",
+                                   % (kind, list(cfg), B, "500,201" if kind == "rir" else "201,500",
                                       "bf16 storage + bf16 MFMA, fp32 accumulate / VQ / losses / master weights"
                                       if args.dtype == "bf16" else "fp32 storage + exact-fp32 MFMA",
-                                      "on" if kind == "speech" else "off"),
+                                      "off" if kind == "rir" else "on"),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "algorithmic_gflop_per_spectrogram": gf},
             "model_tflops": value * gf / 1e3,

@@ -156,6 +156,8 @@ int alvq_adam_dev_f32(float* param, const float* grad, float* exp_avg, float* ex
  * wave (B,S) -> power (B, n_fft/2+1, 1+S/hop).
  * ---------------------------------------------------------------------------------------------- */
 int alvq_stft_power_f32(const float* wave, float* power, int B, int S, int n_fft, int hop, void* stream);
+/* float64 form: the reference's echoed signal is float64 (scipy convolve output, genereate_dataset.py:38-39). */
+int alvq_stft_power_f64(const double* wave, double* power, int B, int S, int n_fft, int hop, void* stream);
 
 /* ================================================================================================
  * bf16 throughput path (BASELINE configs[1]: "batch=64 bf16").  Storage bf16, accumulation fp32.

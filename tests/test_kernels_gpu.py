@@ -206,3 +206,6 @@ def test_stft_power_unpinned(golden_dir):
     torch.manual_seed(10)
     w2 = torch.randn(3, 16000)
     assert rel(N.stft_power(dev(w2)), stft_oracle.stft_power(w2)) < 1e-4
+    w64 = torch.from_numpy(g["wave"]).view(1, -1)                     # float64, as the echoed signal is
+    got64 = N.stft_power(dev(w64))
+    assert got64.dtype == torch.float64 and rel(got64, torch.from_numpy(g["power_f64"])) < 1e-10
