@@ -393,13 +393,21 @@ __global__ __launch_bounds__(256) void bias_grad_nlc_partial_kernel(const u16* d
   }
 }
 
+// dbias[m] (+)= sum_s partial[s][m]; 64 channels x 4 split-phases per workgroup, fixed order.
 __global__ __launch_bounds__(256) void bias_grad_nlc_final_kernel(const float* partial, float* dbias, int splits, int Mp, int M,
                                                                   int accumulate) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
+  const int mi = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + mi;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += partial[(long)k * Mp + m];
-  dbias[m] = accumulate ? dbias[m] + s : s;
+  if (m < M)
+    for (int k = ph; k < splits; k += 4) s += partial[(long)k * Mp + m];
+  __shared__ float red[4][64];
+  red[ph][mi] = s;
+  __syncthreads();
+  if (ph == 0 && m < M) {
+    const float t = (red[0][mi] + red[1][mi]) + (red[2][mi] + red[3][mi]);
+    dbias[m] = accumulate ? dbias[m] + t : t;
+  }
 }
 
 // out = mask > 0 ? dy : 0 on NLC bf16 buffers (whole padded matrix)
@@ -412,6 +420,8 @@ __global__ __launch_bounds__(256) void relu_mask_bf16_kernel(const u16* dy, cons
     ((u16x8*)out)[e] = o;
   }
 }
+
+constexpr int BIAS_SPLITS = 512;   // row ranges of the bias-grad column sums (one workgroup each)
 
 static int wgrad_b_splits(int total_rows, int M, int C, int* chunks_per_split) {
   const int nchunks = (total_rows + WG_R - 1) / WG_R;
@@ -542,7 +552,7 @@ extern "C" int64_t alvq_conv1d_wgrad_bf16_workspace_bytes(int B, int C, int M, i
   int64_t w = (int64_t)splits * KW * M * C * 4;
   const int64_t w2 = conv1d_wgrad_bf16_v2_workspace_bytes(rows, C, M, KW);
   if (w2 > w) w = w2;
-  const int64_t bsz = (int64_t)64 * pad_to(M, TB_K) * 4;
+  const int64_t bsz = (int64_t)BIAS_SPLITS * pad_to(M, TB_K) * 4;
   return w + bsz;
 }
 
@@ -567,9 +577,9 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
     if (rc) return rc;
     if (dbias) {
       float* bpart = (float*)((char*)workspace + wbytes);
-      const int Mp = pad_to(M, TB_K), bs = 64, rps = (rows + bs - 1) / bs;
+      const int Mp = pad_to(M, TB_K), bs = BIAS_SPLITS, rps = (rows + bs - 1) / bs;
       hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
-      hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
+      hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 63) / 64), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
                          accumulate);
       rc = check_launch("alvq_conv1d_wgrad_bf16/bias");
     }
@@ -591,9 +601,9 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
   if (rc) return rc;
   if (dbias) {
     float* bpart = (float*)((char*)workspace + wbytes);
-    const int Mp = pad_to(M, TB_K), bs = 64, rps = (rows + bs - 1) / bs;
+    const int Mp = pad_to(M, TB_K), bs = BIAS_SPLITS, rps = (rows + bs - 1) / bs;
     hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
-    hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
+    hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 63) / 64), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
                        accumulate);
     rc = check_launch("alvq_conv1d_wgrad_bf16/bias");
   }
