@@ -1,0 +1,664 @@
+// Split-bf16 ("bf16x3") convolution and weight-gradient: fp32-grade results on the bf16 matrix cores.
+//
+// gfx950 has no TF32/xf32 MFMA and its exact-fp32 MFMA runs at 1/16 of the bf16 rate.  Here every fp32 value v is
+// carried as two bf16 planes, hi = bf16(v) and lo = bf16(v - hi) (|v - hi - lo| <= 2^-18 |v|), and every product
+// is evaluated as  hi*hi + hi*lo + lo*hi  (three bf16 MFMAs, fp32 accumulation; the lo*lo term, <= 2^-18 relative,
+// is dropped).  bf16 x bf16 products are exact in fp32, so the result differs from an fp32 computation only by
+// ~1e-5 relative -- well inside the 1e-3 parity bar -- at one third of the bf16 MFMA rate, i.e. ~5x the exact-fp32
+// MFMA peak.  Storage cost equals fp32 (two bf16 planes per tensor).
+//
+// Layout: the NLC-padded matrix of include/alvq.h, with the lo plane stored right after the hi plane (guard rows
+// included): lo = hi + alvq_nlc_plane_bytes(B, L, C).  Packed weights likewise (lo image after the hi image).
+//
+// Kernels: same tiling as conv1d_bf16_v2 / conv1d_wgrad_bf16_v2 (256x256 tile, 8 waves; 128x128x3-tap tile for the
+// weight-gradient) with a 2-stage LDS-DMA ring (a K-tile now carries 4 slabs and 96 MFMAs per wave, so one
+// iteration of look-ahead already gives the DMA ~3000 cycles).
+#include <stdlib.h>
+
+#include "alvq_common.h"
+#include "bf16_common.h"
+#include "wgrad_reduce.h"
+
+namespace alvq {
+
+constexpr int X3_M = 256, X3_R = 256, X3_K = 32;
+constexpr int X3_SLAB = X3_M * X3_K * 2;          // 16384 B
+constexpr int X3_STAGE = 4 * X3_SLAB;             // A_hi, A_lo, B_hi, B_lo
+constexpr int X3_LDS = 2 * X3_STAGE;              // 131072 B
+constexpr int X3_CS = X3_M + 4;
+static_assert(64 * X3_CS * 4 <= X3_LDS, "C slab must fit");
+
+struct ConvX3Args {
+  ConvBArgs b;          // hi planes (and everything shared)
+  long x_plane, wp_plane, y_plane;   // element offsets (u16) from a hi pointer to its lo plane
+};
+
+__device__ __forceinline__ void split2(float v, u16& hi, u16& lo) {
+  hi = f2bf(v);
+  lo = f2bf(v - bf2f(hi));
+}
+
+template <int OUT>
+__global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, int KW) {
+  const ConvBArgs& a = ax.b;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int PAD = (KW - 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
+  const int m0 = (tile % a.mtiles) * X3_M;
+  const int r0 = (tile / a.mtiles) * X3_R;
+  const int Cp = a.Cp;
+
+  const int hsel = (lane >> 4) & 3;
+  const int hval = (hsel == 0) ? 0 : (4 - hsel);
+  const int srow = lane >> 2, sgrp = (lane & 3) ^ hval;
+  const long lane_off = (long)srow * Cp + sgrp * 8;
+  const u16* const wbase = a.wp + ((long)m0 + wave * 32) * Cp + lane_off;
+  const u16* const xbase = a.x + ((long)r0 - PAD + wave * 32) * Cp + lane_off;
+  const long tap_w = (long)a.Mp128 * Cp;
+
+  int is_chunk = 0, is_tap = 0;
+  auto issue = [&](int stage) {   // 8 pieces per wave: two per slab
+    unsigned char* dst = lds + stage * X3_STAGE + wave * 2048;
+    const u16* ws = wbase + is_tap * tap_w + is_chunk * X3_K;
+    const u16* xs = xbase + (long)is_tap * Cp + is_chunk * X3_K;
+    glds16(ws, dst);
+    glds16(ws + 16L * Cp, dst + 1024);
+    glds16(ws + ax.wp_plane, dst + X3_SLAB);
+    glds16(ws + ax.wp_plane + 16L * Cp, dst + X3_SLAB + 1024);
+    glds16(xs, dst + 2 * X3_SLAB);
+    glds16(xs + 16L * Cp, dst + 2 * X3_SLAB + 1024);
+    glds16(xs + ax.x_plane, dst + 3 * X3_SLAB);
+    glds16(xs + ax.x_plane + 16L * Cp, dst + 3 * X3_SLAB + 1024);
+    if (++is_tap == KW) {
+      is_tap = 0;
+      ++is_chunk;
+    }
+  };
+
+  const int loff = li * 64 + ((kq ^ ((((li >> 2) & 3) == 0) ? 0 : (4 - ((li >> 2) & 3)))) << 4);
+  const unsigned char* const abase = lds + wm0 * 64 + loff;                       // A_hi; A_lo at + X3_SLAB
+  const unsigned char* const bbase = lds + 2 * X3_SLAB + wn0 * 64 + loff;         // B_hi; B_lo at + X3_SLAB
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n = (Cp / X3_K) * KW;
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < n; ++t) {
+    const int stage = t & 1;
+    if (t + 1 < n) issue(stage ^ 1);     // lands during this K-tile's 96 MFMAs
+    const unsigned char* pa = abase + stage * X3_STAGE;
+    const unsigned char* pb = bbase + stage * X3_STAGE;
+    bf16x8_t ah[8], al[8], bh[4], bl[4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) ah[mi] = *(const bf16x8_t*)(pa + mi * 1024);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bh[ni] = *(const bf16x8_t*)(pb + ni * 1024);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bl[ni] = *(const bf16x8_t*)(pb + X3_SLAB + ni * 1024);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) al[mi] = *(const bf16x8_t*)(pa + X3_SLAB + mi * 1024);   // in flight under hi*lo
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: four 64-row slabs through an fp32 LDS tile
+  float* Cs = (float*)lds;
+  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  for (int slab = 0; slab < 4; ++slab) {
+    if ((wave & 3) == slab) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int rl = ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
+          *(f32x4*)(Cs + rl * X3_CS + ml) = acc[mi][ni];
+        }
+    }
+    __syncthreads();
+    if (OUT == 0) {
+      const int tx = tid & 31, ty = tid >> 5;
+      const int mbase = m0 + tx * 8;
+      if (mbase < a.Mop) {
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && mbase + e < a.M) ? a.bias[mbase + e] : 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int rl = pass * 16 + ty, row = r0 + slab * 64 + rl;
+          int b, l;
+          const bool ok = row_valid(row, Lp1, ndata, &b, &l);
+          const long o = (long)row * a.Mop + mbase;
+          u16x8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = oh, o2h = oh, o2l = oh;
+          if (ok) {
+            float v[8];
+            const f32x4 c0 = *(const f32x4*)(Cs + rl * X3_CS + tx * 8), c1 = *(const f32x4*)(Cs + rl * X3_CS + tx * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = c0[e] + bv[e];
+              v[e + 4] = c1[e] + bv[e + 4];
+            }
+            if (a.skip1) {
+              const u16x8 sh = *(const u16x8*)(a.skip1 + o), sl = *(const u16x8*)(a.skip1 + ax.y_plane + o);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += bf2f(sh[e]) + bf2f(sl[e]);
+            }
+            if (a.skip2) {
+              const u16x8 sh = *(const u16x8*)(a.skip2 + o), sl = *(const u16x8*)(a.skip2 + ax.y_plane + o);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += bf2f(sh[e]) + bf2f(sl[e]);
+            }
+            if (a.relu & 1) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (a.mask) {   // sign of a split value is the sign of its hi plane
+              const u16x8 s = *(const u16x8*)(a.mask + o);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              u16 h, l2;
+              split2(v[e], h, l2);
+              oh[e] = h;
+              ol[e] = l2;
+            }
+            if (a.y2) {
+              const u16x8 sh = *(const u16x8*)(a.post + o), sl = *(const u16x8*)(a.post + ax.y_plane + o);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                u16 h, l2;
+                split2(v[e] + (bf2f(sh[e]) + bf2f(sl[e])), h, l2);
+                o2h[e] = h;
+                o2l[e] = l2;
+              }
+            }
+          }
+          *(u16x8*)(a.y + o) = oh;
+          *(u16x8*)(a.y + ax.y_plane + o) = ol;
+          if (a.y2) {
+            *(u16x8*)(a.y2 + o) = o2h;
+            *(u16x8*)(a.y2 + ax.y_plane + o) = o2l;
+          }
+        }
+      }
+    } else {
+      const int rl = tid & 63, row = r0 + slab * 64 + rl;
+      int b, l;
+      if (row_valid(row, Lp1, ndata, &b, &l)) {
+        for (int ml = tid >> 6; ml < X3_M; ml += 8) {
+          const int m = m0 + ml;
+          if (m >= a.M) break;
+          a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * X3_CS + ml] + (a.bias ? a.bias[m] : 0.f);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------- weight-gradient
+struct WgradX3Args {
+  const u16* dy;
+  const u16* x;
+  float* partial;
+  long dy_plane, x_plane;
+  int Mp, Cp, M, C;
+  int mtiles, ctiles, splits, chunks_per_split, total_rows;
+};
+
+typedef unsigned long long u64x;
+template <int ROW_BYTES>
+__device__ __forceinline__ void tr_issue(unsigned lds_addr, u64x& lo, u64x& hi) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(lds_addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds_addr), "n"(16 * ROW_BYTES));
+}
+__device__ __forceinline__ bf16x8_t tr_join(u64x lo, u64x hi) {
+  typedef u64x u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 v = {lo, hi};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int KW, int NCF>
+__global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args a) {
+  constexpr int PAD = (KW - 1) / 2;
+  constexpr int MT = 128, CT = 4 * NCF * 16;
+  constexpr int YRB = MT * 2, XRB = CT * 2;
+  constexpr int XROWS = KW == 1 ? 32 : 36;
+  constexpr int YBYTES = 32 * YRB, XBYTES = XROWS * XRB;
+  constexpr int STAGE = 2 * YBYTES + 2 * XBYTES;      // dY_hi, dY_lo, X_hi, X_lo
+  constexpr int XPIECES = XBYTES / 1024, XROWS_PER_PIECE = 1024 / XRB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 64, wc0 = (wave & 3) * NCF * 16;
+  const int ntile = a.mtiles * a.ctiles;
+  const int id = xcd_remap(blockIdx.x, ntile * a.splits);
+  const int split = id / ntile, t_id = id % ntile;
+  const int m0 = (t_id / a.ctiles) * MT, c0 = (t_id % a.ctiles) * CT;
+  const int rbeg = split * a.chunks_per_split * 64;
+  const int rend = min(a.total_rows, rbeg + a.chunks_per_split * 64);
+  const int n = (rend - rbeg) / 32;
+
+  const int y_r = lane >> 4, y_s = lane & 15;
+  const int x_r = (lane * 16) / XRB, x_s = ((lane * 16) % XRB) >> 4;
+  auto src_slot = [](int slot, int row) { return (slot & 16) | (((((slot >> 1) & 7) ^ (row & 7)) << 1) | (slot & 1)); };
+  const int last_row = a.total_rows - 1;
+  int is_row = rbeg;
+  auto issue = [&](int stage) {
+    unsigned char* dst = lds + stage * STAGE;
+    {
+      const int lr = 4 * wave + y_r;
+      const int mcol = min(m0 + src_slot(y_s, lr) * 8, a.Mp - 8);
+      const u16* src = a.dy + (long)(is_row + lr) * a.Mp + mcol;
+      glds16(src, dst + wave * 1024);
+      glds16(src + a.dy_plane, dst + YBYTES + wave * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < (XPIECES + 7) / 8; ++q) {
+      const int p = wave + 8 * q;
+      if (p < XPIECES) {
+        const int lr = p * XROWS_PER_PIECE + x_r;
+        int gr = is_row - PAD + lr;
+        gr = gr < 0 ? 0 : (gr > last_row ? last_row : gr);
+        const int ccol = min(c0 + src_slot(x_s, lr) * 8, a.Cp - 8);
+        const u16* src = a.x + (long)gr * a.Cp + ccol;
+        glds16(src, dst + 2 * YBYTES + p * 1024);
+        glds16(src + a.x_plane, dst + 2 * YBYTES + XBYTES + p * 1024);
+      }
+    }
+    is_row += 32;
+  };
+
+  const int g = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int krow = 4 * g + q4;
+  int ybase, xbase[KW];
+  ybase = krow * YRB + ((krow & 7) << 5) + p4 * 8;
+#pragma unroll
+  for (int t = 0; t < KW; ++t) xbase[t] = (krow + t) * XRB + (((krow + t) & 7) << 5) + p4 * 8;
+  int yseg[4], xseg[NCF], xline[NCF];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) yseg[mi] = ((wm0 >> 4) + mi) << 5;
+#pragma unroll
+  for (int cf = 0; cf < NCF; ++cf) {
+    const int cb = (wc0 >> 4) + cf;
+    xseg[cf] = (cb & 7) << 5;
+    xline[cf] = (cb >> 3) * 256;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds;
+
+  f32x4 acc[KW][4][NCF];
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NCF; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (n > 0) {
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < n; ++t) {
+      const int stage = t & 1;
+      if (t + 1 < n) issue(stage ^ 1);
+      const unsigned ys = lds0 + stage * STAGE, xs = ys + 2 * YBYTES;
+      u64x ahl[4], ahh[4], all_[4], alh[4], bhl[KW][NCF], bhh[KW][NCF], bll[KW][NCF], blh[KW][NCF];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        tr_issue<YRB>(ys + (ybase ^ yseg[mi]), ahl[mi], ahh[mi]);
+        tr_issue<YRB>(ys + YBYTES + (ybase ^ yseg[mi]), all_[mi], alh[mi]);
+      }
+#pragma unroll
+      for (int tp = 0; tp < KW; ++tp)
+#pragma unroll
+        for (int cf = 0; cf < NCF; ++cf) {
+          const unsigned off = (xbase[tp] ^ xseg[cf]) + xline[cf];
+          tr_issue<XRB>(xs + off, bhl[tp][cf], bhh[tp][cf]);
+          tr_issue<XRB>(xs + XBYTES + off, bll[tp][cf], blh[tp][cf]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const bf16x8_t ah = tr_join(ahl[mi], ahh[mi]), al = tr_join(all_[mi], alh[mi]);
+#pragma unroll
+        for (int tp = 0; tp < KW; ++tp)
+#pragma unroll
+          for (int cf = 0; cf < NCF; ++cf) {
+            const bf16x8_t bh = tr_join(bhl[tp][cf], bhh[tp][cf]), bl = tr_join(bll[tp][cf], blh[tp][cf]);
+            f32x4 c = acc[tp][mi][cf];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+            acc[tp][mi][cf] = c;
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  const int li = lane & 15, kq = lane >> 4;
+  float* out = a.partial + (long)split * KW * a.M * a.C;
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm0 + mi * 16 + kq * 4 + r;
+          const int c = c0 + wc0 + cf * 16 + li;
+          if (m < a.M && c < a.C) out[((long)t * a.M + m) * a.C + c] = acc[t][mi][cf][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------- helpers (split forms)
+__global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* w, u16* wp, long plane, int M, int C, int KW, int Mp,
+                                                             int Cp, int w_layout) {
+  const long total = (long)KW * Mp * Cp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % Cp);
+    const int m = (int)((e / Cp) % Mp);
+    const int t = (int)(e / ((long)Cp * Mp));
+    float v = 0.f;
+    if (m < M && c < C) v = w_layout == ALVQ_W_OIK ? w[((long)m * C + c) * KW + t] : w[((long)c * M + m) * KW + (KW - 1 - t)];
+    u16 hi, lo;
+    split2(v, hi, lo);
+    wp[e] = hi;
+    wp[plane + e] = lo;
+  }
+}
+
+__global__ __launch_bounds__(256) void ncl_to_nlc_x3_kernel(const float* x, u16* y, long plane, int B, int C, int L, int Cp,
+                                                            int rows_total) {
+  __shared__ float tile[32][33];
+  const int ct = Cp / 32;
+  const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int Lp1 = L + 1, ndata = B * Lp1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, row = r0 + tx;
+    int b, l;
+    const bool ok = row_valid(row, Lp1, ndata, &b, &l) && c < C;
+    tile[ty + 8 * i][tx] = ok ? x[((long)b * C + c) * L + l] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = r0 + ty + 8 * i, c = c0 + tx;
+    if (row < rows_total) {
+      u16 hi, lo;
+      split2(tile[tx][ty + 8 * i], hi, lo);
+      y[(long)row * Cp + c] = hi;
+      y[plane + (long)row * Cp + c] = lo;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void nlc_to_ncl_x3_kernel(const u16* x, long plane, float* y, int B, int C, int L, int Cp,
+                                                            int rows_total) {
+  __shared__ float tile[32][33];
+  const int ct = Cp / 32;
+  const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int Lp1 = L + 1, ndata = B * Lp1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = row < rows_total ? bf2f(x[(long)row * Cp + c]) + bf2f(x[plane + (long)row * Cp + c]) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, row = r0 + tx;
+    int b, l;
+    if (row_valid(row, Lp1, ndata, &b, &l) && c < C) y[((long)b * C + c) * L + l] = tile[tx][ty + 8 * i];
+  }
+}
+
+// out = t > 0 ? dy : 0 on both planes (the sign of a split value is the sign of its hi plane)
+__global__ __launch_bounds__(256) void relu_mask_x3_kernel(const u16* dy, const u16* t, u16* out, long plane8, long n8) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n8; e += (long)gridDim.x * 256) {
+    const u16x8 dh = ((const u16x8*)dy)[e], dl = ((const u16x8*)dy)[plane8 + e], m = ((const u16x8*)t)[e];
+    u16x8 oh, ol;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool keep = bf2f(m[i]) > 0.f;
+      oh[i] = keep ? dh[i] : (u16)0;
+      ol[i] = keep ? dl[i] : (u16)0;
+    }
+    ((u16x8*)out)[e] = oh;
+    ((u16x8*)out)[plane8 + e] = ol;
+  }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_x3_partial_kernel(const u16* dy, long plane, float* partial, int rows, int Mp,
+                                                                   int rows_per_split) {
+  const int groups = Mp / 8;
+  const int gpb = groups < 256 ? groups : 256;
+  const int rsub = 256 / gpb;
+  const int gi = threadIdx.x % gpb, rp = threadIdx.x / gpb;
+  const int grp = blockIdx.x * gpb + gi;
+  const int rb = blockIdx.y * rows_per_split, re = min(rows, rb + rows_per_split);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (grp < groups && rp < rsub)
+    for (int r = rb + rp; r < re; r += rsub) {
+      const u16x8 vh = *(const u16x8*)(dy + (long)r * Mp + grp * 8), vl = *(const u16x8*)(dy + plane + (long)r * Mp + grp * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += bf2f(vh[e]) + bf2f(vl[e]);
+    }
+  __shared__ float red[256][9];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+  __syncthreads();
+  if (rp == 0 && grp < groups) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      for (int k = 0; k < rsub; ++k) t += red[k * gpb + gi][e];
+      partial[(long)blockIdx.y * Mp + grp * 8 + e] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_x3_final_kernel(const float* partial, float* dbias, int splits, int Mp, int M,
+                                                                 int accumulate) {
+  const int mi = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + mi;
+  float s = 0.f;
+  if (m < M)
+    for (int k = ph; k < splits; k += 4) s += partial[(long)k * Mp + m];
+  __shared__ float red[4][64];
+  red[ph][mi] = s;
+  __syncthreads();
+  if (ph == 0 && m < M) {
+    const float t = (red[0][mi] + red[1][mi]) + (red[2][mi] + red[3][mi]);
+    dbias[m] = accumulate ? dbias[m] + t : t;
+  }
+}
+
+template <int KW, int NCF>
+static constexpr int wgrad_x3_lds() {
+  return 2 * (2 * 32 * 256 + 2 * (KW == 1 ? 32 : 36) * (4 * NCF * 16 * 2));
+}
+
+static int wgrad_x3_splits(int total_rows, int tiles, int* chunks_per_split) {
+  const int nchunks = total_rows / 64;
+  int want = (256 + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  if (want > nchunks) want = nchunks;
+  if (want > 64) want = 64;
+  const int cps = (nchunks + want - 1) / want;
+  *chunks_per_split = cps;
+  return (nchunks + cps - 1) / cps;
+}
+
+constexpr int X3_BIAS_SPLITS = 512;
+
+}  // namespace alvq
+
+using namespace alvq;
+
+static inline int pad_to(int x, int q) { return (x + q - 1) / q * q; }
+static inline long nlc_plane_elems(int B, int L, int C) {
+  return ((long)alvq_nlc_rows(B, L) + 2L * alvq_nlc_guard_rows()) * pad_to(C, 64);
+}
+
+extern "C" int64_t alvq_nlc_plane_bytes(int B, int L, int C) {
+  return (B <= 0 || L <= 0 || C <= 0) ? -1 : nlc_plane_elems(B, L, C) * 2;
+}
+
+extern "C" int alvq_pack_weight_bf16x3(const float* w, void* wp, int M, int C, int KW, int w_layout, void* stream) {
+  ALVQ_REQUIRE(w && wp, ALVQ_EINVAL, "alvq_pack_weight_bf16x3: null pointer");
+  ALVQ_REQUIRE(M > 0 && C > 0 && (KW == 1 || KW == 3), ALVQ_EINVAL, "alvq_pack_weight_bf16x3: bad dims");
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_pack_weight_bf16x3: w_layout");
+  const long total = alvq_packed_weight_elems(M, C, KW);
+  int grid = (int)((total + 1023) / 1024);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pack_weight_x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (u16*)wp, total, M, C, KW,
+                     pad_to(M, WP_ROWS), pad_to(C, 64), w_layout);
+  return check_launch("alvq_pack_weight_bf16x3");
+}
+
+extern "C" int alvq_ncl_to_nlc_bf16x3(const float* x, void* y, int B, int C, int L, void* stream) {
+  ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_ncl_to_nlc_bf16x3: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_ncl_to_nlc_bf16x3: bad dims");
+  const int Cp = pad_to(C, 64), rows = (int)alvq_nlc_rows(B, L);
+  hipLaunchKernelGGL(ncl_to_nlc_x3_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y,
+                     nlc_plane_elems(B, L, C), B, C, L, Cp, rows);
+  return check_launch("alvq_ncl_to_nlc_bf16x3");
+}
+
+extern "C" int alvq_nlc_to_ncl_bf16x3(const void* x, float* y, int B, int C, int L, void* stream) {
+  ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_nlc_to_ncl_bf16x3: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_nlc_to_ncl_bf16x3: bad dims");
+  const int Cp = pad_to(C, 64), rows = (int)alvq_nlc_rows(B, L);
+  hipLaunchKernelGGL(nlc_to_ncl_x3_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, (const u16*)x,
+                     nlc_plane_elems(B, L, C), y, B, C, L, Cp, rows);
+  return check_launch("alvq_nlc_to_ncl_bf16x3");
+}
+
+extern "C" int alvq_relu_mask_bf16x3(const void* dy, const void* t, void* out, int B, int C, int L, void* stream) {
+  ALVQ_REQUIRE(dy && t && out, ALVQ_EINVAL, "alvq_relu_mask_bf16x3: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_relu_mask_bf16x3: bad dims");
+  const long n = (long)alvq_nlc_rows(B, L) * pad_to(C, 64);
+  long g = (n / 8 + 1023) / 1024;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(relu_mask_x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, (const u16*)t,
+                     (u16*)out, nlc_plane_elems(B, L, C) / 8, n / 8);
+  return check_launch("alvq_relu_mask_bf16x3");
+}
+
+extern "C" int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
+                                  const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M,
+                                  int L, int KW, int relu, void* stream) {
+  ALVQ_REQUIRE(x && wp && (y || y_ncl), ALVQ_EINVAL, "alvq_conv1d_bf16x3: null x/wp/y");
+  ALVQ_REQUIRE(!(y && y_ncl), ALVQ_EINVAL, "alvq_conv1d_bf16x3: choose one of y (NLC) and y_ncl (NCL fp32)");
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_bf16x3: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16x3: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE((y2 == nullptr) == (post == nullptr), ALVQ_EINVAL, "alvq_conv1d_bf16x3: y2 and post go together");
+  ALVQ_REQUIRE(!y_ncl || (!skip1 && !skip2 && !mask && !post && !relu), ALVQ_EUNSUPPORTED,
+               "alvq_conv1d_bf16x3: the NCL fp32 epilogue fuses bias only");
+  ALVQ_REQUIRE((long)B * (L + 1) < (1L << 30), ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16x3: problem too large");
+  const long rows = alvq_nlc_rows(B, L);
+  ConvX3Args a{{(const u16*)x, (const u16*)wp, bias, (const u16*)skip1, (const u16*)skip2, (const u16*)mask, (const u16*)post,
+                (u16*)y, (u16*)y2, y_ncl, B, L, pad_to(C, 64), M, pad_to(M, 64), pad_to(M, WP_ROWS), relu ? 1 : 0,
+                (int)(rows / X3_R), pad_to(M, X3_M) / X3_M},
+               nlc_plane_elems(B, L, C), (long)alvq_packed_weight_elems(M, C, KW), nlc_plane_elems(B, L, M)};
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    attr = true;
+  }
+  const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
+  if (y) hipLaunchKernelGGL((conv1d_bf16x3_kernel<0>), grid, block, X3_LDS, s, a, KW);
+  else hipLaunchKernelGGL((conv1d_bf16x3_kernel<1>), grid, block, X3_LDS, s, a, KW);
+  return check_launch("alvq_conv1d_bf16x3");
+}
+
+extern "C" int64_t alvq_conv1d_wgrad_bf16x3_workspace_bytes(int B, int C, int M, int L, int KW) {
+  if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3)) return -1;
+  const int rows = (int)alvq_nlc_rows(B, L);
+  const int ct = KW == 3 ? 128 : 256;
+  int cps;
+  const int splits = wgrad_x3_splits(rows, ((M + 127) / 128) * ((C + ct - 1) / ct), &cps);
+  return (int64_t)splits * KW * M * C * 4 + (int64_t)X3_BIAS_SPLITS * pad_to(M, 64) * 4;
+}
+
+extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C,
+                                        int M, int L, int KW, int w_layout, int accumulate, void* stream) {
+  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16x3: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: w_layout");
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = (int)alvq_nlc_rows(B, L);
+  const int ct = KW == 3 ? 128 : 256;
+  WgradX3Args a{(const u16*)dy, (const u16*)x, (float*)workspace, nlc_plane_elems(B, L, M), nlc_plane_elems(B, L, C),
+                pad_to(M, 64), pad_to(C, 64), M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, rows};
+  a.splits = wgrad_x3_splits(rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16x3_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_x3_lds<3, 2>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16x3_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_x3_lds<1, 4>());
+    attr = true;
+  }
+  const int grid = a.mtiles * a.ctiles * a.splits;
+  if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_bf16x3_kernel<3, 2>), dim3(grid), dim3(512), (wgrad_x3_lds<3, 2>()), s, a);
+  else hipLaunchKernelGGL((conv1d_wgrad_bf16x3_kernel<1, 4>), dim3(grid), dim3(512), (wgrad_x3_lds<1, 4>()), s, a);
+  int rc = check_launch("alvq_conv1d_wgrad_bf16x3");
+  if (rc) return rc;
+  const long total = (long)KW * M * C;
+  int rgrid = (int)((total + 255) / 256);
+  if (rgrid > 2048) rgrid = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, a.splits, KW, M, C, w_layout,
+                     accumulate);
+  rc = check_launch("alvq_conv1d_wgrad_bf16x3/reduce");
+  if (rc) return rc;
+  if (dbias) {
+    float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
+    const int Mp = pad_to(M, 64), bs = X3_BIAS_SPLITS, rps = (rows + bs - 1) / bs;
+    hipLaunchKernelGGL(bias_grad_x3_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, a.dy_plane,
+                       bpart, rows, Mp, rps);
+    hipLaunchKernelGGL(bias_grad_x3_final_kernel, dim3((M + 63) / 64), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
+                       accumulate);
+    rc = check_launch("alvq_conv1d_wgrad_bf16x3/bias");
+  }
+  return rc;
+}

@@ -61,6 +61,14 @@ _SIGNATURES = {
     "alvq_conv1d_bf16": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p]),
     "alvq_conv1d_wgrad_bf16_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_bf16": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
+    "alvq_nlc_plane_bytes": (_i64, [_i32, _i32, _i32]),
+    "alvq_pack_weight_bf16x3": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_ncl_to_nlc_bf16x3": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
+    "alvq_nlc_to_ncl_bf16x3": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
+    "alvq_relu_mask_bf16x3": (_i32, [_c_void_p] * 3 + [_i32, _i32, _i32, _c_void_p]),
+    "alvq_conv1d_bf16x3": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p]),
+    "alvq_conv1d_wgrad_bf16x3_workspace_bytes": (_i64, [_i32] * 5),
+    "alvq_conv1d_wgrad_bf16x3": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -360,21 +368,22 @@ def stft_power(wave, n_fft=400, hop=160):
 # ----------------------------------------------------------------------------------------------- bf16 path
 class NLC:
     """A bf16 activation in the NLC-padded layout (see include/alvq.h): storage = guard rows + matrix + guard rows."""
-    __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard")
+    __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard", "planes")
 
-    def __init__(self, B, L, C, device):
+    def __init__(self, B, L, C, device, planes=1):
+        """planes=2: the split-bf16 form (hi plane, then the lo plane at +alvq_nlc_plane_bytes)."""
         L_ = lib()
-        self.B, self.L, self.C = B, L, C
+        self.B, self.L, self.C, self.planes = B, L, C, planes
         self.Cp = L_.alvq_nlc_channels(C)
         self.rows = L_.alvq_nlc_rows(B, L)
         self.guard = L_.alvq_nlc_guard_rows()
-        self.storage = torch.empty(((self.rows + 2 * self.guard) * self.Cp,), device=device, dtype=torch.bfloat16)
+        self.storage = torch.empty((planes * (self.rows + 2 * self.guard) * self.Cp,), device=device, dtype=torch.bfloat16)
 
     @classmethod
-    def wrap(cls, storage, B, L, C):
+    def wrap(cls, storage, B, L, C, planes=1):
         self = cls.__new__(cls)
         L_ = lib()
-        self.B, self.L, self.C = B, L, C
+        self.B, self.L, self.C, self.planes = B, L, C, planes
         self.Cp, self.rows, self.guard = L_.alvq_nlc_channels(C), L_.alvq_nlc_rows(B, L), L_.alvq_nlc_guard_rows()
         self.storage = storage
         return self
@@ -383,67 +392,86 @@ class NLC:
     def ptr(self):
         return self.storage.data_ptr() + self.guard * self.Cp * 2
 
-    def matrix(self):
-        g = self.guard * self.Cp
+    def matrix(self, plane=0):
+        g = (self.guard + plane * (self.rows + 2 * self.guard)) * self.Cp
         return self.storage[g:g + self.rows * self.Cp].view(self.rows, self.Cp)
 
     def to_ncl(self):
         """(B,C,L) fp32 copy -- test/debug helper (torch indexing, not on the hot path)."""
-        m = self.matrix()[1:1 + self.B * (self.L + 1)].view(self.B, self.L + 1, self.Cp)
-        return m[:, :self.L, :self.C].permute(0, 2, 1).float().contiguous()
+        m = self.matrix(0).float()
+        if self.planes == 2:
+            m = m + self.matrix(1).float()
+        m = m[1:1 + self.B * (self.L + 1)].view(self.B, self.L + 1, self.Cp)
+        return m[:, :self.L, :self.C].permute(0, 2, 1).contiguous()
 
 
 def nlc_like(ref, C):
-    return NLC(ref.B, ref.L, C, ref.storage.device)
+    return NLC(ref.B, ref.L, C, ref.storage.device, ref.planes)
 
 
 def _nlc_ptr(t, ref, C, name):
     if t is None:
         return None
-    if not isinstance(t, NLC) or (t.B, t.L, t.C) != (ref.B, ref.L, C):
-        raise RuntimeError("%s: expected an NLC activation of (B=%d, L=%d, C=%d)" % (name, ref.B, ref.L, C))
+    if not isinstance(t, NLC) or (t.B, t.L, t.C, t.planes) != (ref.B, ref.L, C, ref.planes):
+        raise RuntimeError("%s: expected an NLC activation of (B=%d, L=%d, C=%d, planes=%d)" % (name, ref.B, ref.L, C, ref.planes))
     return t.ptr
 
 
-def ncl_to_nlc(x):
-    """(B,C,L) fp32 dense -> NLC bf16."""
+def ncl_to_nlc(x, planes=1):
+    """(B,C,L) fp32 dense -> NLC bf16 (planes=2: split hi/lo)."""
     B, C, L = x.shape
-    out = NLC(B, L, C, x.device)
-    _check(lib().alvq_ncl_to_nlc_bf16(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16")
+    out = NLC(B, L, C, x.device, planes)
+    if planes == 2:
+        _check(lib().alvq_ncl_to_nlc_bf16x3(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16x3")
+    else:
+        _check(lib().alvq_ncl_to_nlc_bf16(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16")
     return out
 
 
 def nlc_to_ncl(a):
     """NLC bf16 -> (B,C,L) fp32 dense."""
     y = torch.empty((a.B, a.C, a.L), device=a.storage.device, dtype=torch.float32)
-    _check(lib().alvq_nlc_to_ncl_f32(a.ptr, _ptr(y), a.B, a.C, a.L, _stream()), "alvq_nlc_to_ncl_f32")
+    if a.planes == 2:
+        _check(lib().alvq_nlc_to_ncl_bf16x3(a.ptr, _ptr(y), a.B, a.C, a.L, _stream()), "alvq_nlc_to_ncl_bf16x3")
+    else:
+        _check(lib().alvq_nlc_to_ncl_f32(a.ptr, _ptr(y), a.B, a.C, a.L, _stream()), "alvq_nlc_to_ncl_f32")
     return y
 
 
-def pack_weight(w, w_layout):
-    """fp32 weight (M,C,KW) [OIK] or (C,M,KW) [IOK] -> packed bf16 image + (M, C, KW)."""
+def pack_weight(w, w_layout, planes=1):
+    """fp32 weight (M,C,KW) [OIK] or (C,M,KW) [IOK] -> packed bf16 image(s) + (M, C, KW, planes)."""
     if w_layout == W_OIK:
         M, C, KW = w.shape
     else:
         C, M, KW = w.shape
     n = lib().alvq_packed_weight_elems(M, C, KW)
-    wp = torch.empty((n,), device=w.device, dtype=torch.bfloat16)
-    _check(lib().alvq_pack_weight_bf16(_ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout, _stream()), "alvq_pack_weight_bf16")
-    return wp, (M, C, KW)
+    wp = torch.empty((planes * n,), device=w.device, dtype=torch.bfloat16)
+    if planes == 2:
+        _check(lib().alvq_pack_weight_bf16x3(_ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout, _stream()), "alvq_pack_weight_bf16x3")
+    else:
+        _check(lib().alvq_pack_weight_bf16(_ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout, _stream()), "alvq_pack_weight_bf16")
+    return wp, (M, C, KW, planes)
 
 
 def relu_mask_bf16(dy, t):
     out = nlc_like(dy, dy.C)
-    n = dy.rows * dy.Cp
-    _check(lib().alvq_relu_mask_bf16(dy.ptr, _nlc_ptr(t, dy, dy.C, "t"), out.ptr, n, _stream()), "alvq_relu_mask_bf16")
+    if dy.planes == 2:
+        _check(lib().alvq_relu_mask_bf16x3(dy.ptr, _nlc_ptr(t, dy, dy.C, "t"), out.ptr, dy.B, dy.C, dy.L, _stream()),
+               "alvq_relu_mask_bf16x3")
+    else:
+        n = dy.rows * dy.Cp
+        _check(lib().alvq_relu_mask_bf16(dy.ptr, _nlc_ptr(t, dy, dy.C, "t"), out.ptr, n, _stream()), "alvq_relu_mask_bf16")
     return out
 
 
 def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, out_ncl=False):
     """x: NLC; packed = pack_weight(...).  Returns NLC y, (y, y2) with post, or a (B,M,L) fp32 tensor if out_ncl."""
-    wp, (M, C, KW) = packed
+    wp, (M, C, KW, wplanes) = packed
     if C != x.C:
         raise RuntimeError("conv1d_bf16: weight expects %d input channels, x has %d" % (C, x.C))
+    if wplanes != x.planes:
+        raise RuntimeError("conv1d_bf16: weight packed with %d plane(s), activation has %d" % (wplanes, x.planes))
+    split = x.planes == 2
     if bias is not None and bias.numel() != M:
         raise RuntimeError("conv1d_bf16: bias has %d elements, expected %d" % (bias.numel(), M))
     y = y2 = y_ncl = None
@@ -453,9 +481,13 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
         y = nlc_like(x, M)
         y2 = nlc_like(x, M) if post is not None else None
     # same dispatch rule as alvq_conv1d_bf16: wide layers run the 256x256-tile kernel
-    family = "conv1d_bf16_v2_kernel" if ((M + 255) // 256 * 256 - M) <= 32 else "conv1d_bf16_kernel"
+    if split:
+        family, fn = "conv1d_bf16x3_kernel", lib().alvq_conv1d_bf16x3
+    else:
+        family = "conv1d_bf16_v2_kernel" if ((M + 255) // 256 * 256 - M) <= 32 else "conv1d_bf16_kernel"
+        fn = lib().alvq_conv1d_bf16
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
-        rc = lib().alvq_conv1d_bf16(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),
+        rc = fn(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),
                                     _nlc_ptr(skip2, x, M, "skip2"), _nlc_ptr(mask, x, M, "mask"),
                                     _nlc_ptr(post, x, M, "post"), y.ptr if y is not None else None,
                                     y2.ptr if y2 is not None else None, _ptr(y_ncl), x.B, C, M, x.L, KW,
@@ -478,9 +510,15 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
         raise RuntimeError("conv1d_wgrad_bf16: dw_out has shape %s, expected %s" % (tuple(dw_out.shape), shape))
     if want_bias and dbias_out is None:
         dbias_out = torch.empty((M,), device=dev, dtype=torch.float32)
-    ws = _workspace(lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x.B, C, M, x.L, KW), dev)
-    with _timed("conv1d_wgrad_bf16_v2_kernel", 2.0 * x.B * x.L * M * C * KW):
-        rc = lib().alvq_conv1d_wgrad_bf16(dy.ptr, x.ptr, _ptr(dw_out, name="dw"),
+    if dy.planes != x.planes:
+        raise RuntimeError("conv1d_wgrad_bf16: dy and x differ in planes")
+    if x.planes == 2:
+        family, fn, wsfn = "conv1d_wgrad_bf16x3_kernel", lib().alvq_conv1d_wgrad_bf16x3, lib().alvq_conv1d_wgrad_bf16x3_workspace_bytes
+    else:
+        family, fn, wsfn = "conv1d_wgrad_bf16_v2_kernel", lib().alvq_conv1d_wgrad_bf16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes
+    ws = _workspace(wsfn(x.B, C, M, x.L, KW), dev)
+    with _timed(family, 2.0 * x.B * x.L * M * C * KW):
+        rc = fn(dy.ptr, x.ptr, _ptr(dw_out, name="dw"),
                                           _ptr(dbias_out, name="dbias") if want_bias else None, ws.data_ptr(),
                                           x.B, C, M, x.L, KW, w_layout, int(bool(accumulate)), _stream())
     _check(rc, "alvq_conv1d_wgrad_bf16")

@@ -11,9 +11,13 @@ Two precisions share these chains through a small "engine" object:
 * ``f32``  -- activations (B,C,L) fp32 exactly as the reference lays them out, exact-fp32 MFMA (parity mode);
 * ``bf16`` -- activations in the NLC-padded bf16 layout between convs, bf16 MFMA with fp32 accumulation
   (BASELINE configs[1]); module inputs/outputs, the quantiser, losses, gradients of parameters and the
-  optimiser state stay fp32.
+  optimiser state stay fp32;
+* ``bf16x3`` -- the same pipeline with every tensor split into two bf16 planes (hi, lo) and every product
+  evaluated as hi*hi + hi*lo + lo*hi: fp32-grade parity (~1e-5) at a third of the bf16 MFMA rate, i.e. several
+  times the exact-fp32 MFMA that gfx950 offers (it has no TF32/xf32).
 
-Select with ``set_compute_dtype("f32" | "bf16")`` or the environment variable ``ALVQ_DTYPE`` (default f32).
+Select with ``set_compute_dtype("f32" | "bf16" | "bf16x3")`` or the environment variable ``ALVQ_DTYPE``
+(default f32).
 """
 from __future__ import annotations
 
@@ -31,8 +35,8 @@ _DTYPE = os.environ.get("ALVQ_DTYPE", "f32")
 
 def set_compute_dtype(name):
     global _DTYPE
-    if name not in ("f32", "bf16"):
-        raise ValueError("compute dtype must be 'f32' or 'bf16', got %r" % (name,))
+    if name not in ("f32", "bf16", "bf16x3"):
+        raise ValueError("compute dtype must be 'f32', 'bf16' or 'bf16x3', got %r" % (name,))
     _DTYPE = name
 
 
@@ -87,6 +91,7 @@ class _F32Engine:
 
 class _BF16Engine:
     name = "bf16"
+    planes = 1
 
     def __init__(self):
         self._packed = {}
@@ -95,11 +100,11 @@ class _BF16Engine:
         key = (w.data_ptr(), layout)
         pk = self._packed.get(key)
         if pk is None:
-            pk = self._packed[key] = N.pack_weight(w.detach(), layout)
+            pk = self._packed[key] = N.pack_weight(w.detach(), layout, self.planes)
         return pk
 
     def enter(self, x):
-        return N.ncl_to_nlc(dense(x))
+        return N.ncl_to_nlc(dense(x), self.planes)
 
     def leave(self, a):
         return N.nlc_to_ncl(a)
@@ -114,14 +119,20 @@ class _BF16Engine:
         return N.relu_mask_bf16(dy, t)
 
     def pack(self, act):
-        return act.storage, (act.B, act.L, act.C)
+        return act.storage, (act.B, act.L, act.C, act.planes)
 
     def unpack(self, tensor, meta):
         return N.NLC.wrap(tensor, *meta)
 
 
+class _BF16x3Engine(_BF16Engine):
+    name = "bf16x3"
+    planes = 2
+
+
 def _engine(name=None):
-    return _BF16Engine() if (name or _DTYPE) == "bf16" else _F32Engine()
+    name = name or _DTYPE
+    return _BF16x3Engine() if name == "bf16x3" else _BF16Engine() if name == "bf16" else _F32Engine()
 
 
 def _save(ctx, eng, tensors, acts):

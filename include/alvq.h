@@ -197,6 +197,26 @@ int64_t alvq_conv1d_wgrad_bf16_workspace_bytes(int B, int C, int M, int L, int K
 int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
                            int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
 
+/* ================================================================================================
+ * Split-bf16 ("bf16x3") path: fp32-grade results on the bf16 matrix cores (gfx950 has no TF32/xf32 and its
+ * exact-fp32 MFMA runs at 1/16 of the bf16 rate).  Every value is two bf16 planes, hi = bf16(v) and
+ * lo = bf16(v - hi); products are hi*hi + hi*lo + lo*hi with fp32 accumulation (~1e-5 relative).
+ * An NLC-padded operand's lo plane follows its hi plane (guard rows included) at +alvq_nlc_plane_bytes(B,L,C);
+ * a packed weight's lo image follows its hi image at +2*alvq_packed_weight_elems(M,C,KW) bytes.  Pointers passed
+ * below point at row 0 of the hi plane.  Same contracts as the bf16 entry points of the same name.
+ * ============================================================================================== */
+int64_t alvq_nlc_plane_bytes(int B, int L, int C);
+int alvq_pack_weight_bf16x3(const float* w, void* wp, int M, int C, int KW, int w_layout, void* stream);
+int alvq_ncl_to_nlc_bf16x3(const float* x, void* y, int B, int C, int L, void* stream);
+int alvq_nlc_to_ncl_bf16x3(const void* x, float* y, int B, int C, int L, void* stream);
+int alvq_relu_mask_bf16x3(const void* dy, const void* t, void* out, int B, int C, int L, void* stream);
+int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
+                       const void* mask, const void* post, void* y, void* y2, float* y_ncl,
+                       int B, int C, int M, int L, int KW, int relu, void* stream);
+int64_t alvq_conv1d_wgrad_bf16x3_workspace_bytes(int B, int C, int M, int L, int KW);
+int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
+                             int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
