@@ -12,7 +12,7 @@
 
 namespace alvq {
 
-constexpr int VQ_RB = 64;    // rows per workgroup (16 per wave)
+constexpr int VQ_RB_MAX = 128;  // rows per workgroup: 16 per wave, 4 or 8 waves
 constexpr int VQ_CT = 128;   // codes per tile
 constexpr int VQ_DK = 32;    // dims per staged chunk
 constexpr int VQ_ES = 34;    // Es row stride: 34*li mod 32 = 2*li -> conflict-free with kq in {0,1}
@@ -45,7 +45,11 @@ struct ArgminArgs {
   int K, D, Dp, XSTR;
 };
 
-__global__ __launch_bounds__(256, 2) void vq_argmin_f32_kernel(ArgminArgs a) {
+// NW waves per workgroup, 16 rows each.  NW = 4 for D <= 128 (50 KB LDS, three workgroups per CU); NW = 8 for wider
+// rows, where the stationary block would otherwise allow one 4-wave workgroup per CU (one wave per SIMD).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void vq_argmin_f32_kernel(ArgminArgs a) {
+  constexpr int NT = 64 * NW, VQ_RB = 16 * NW, EPT = VQ_CT * VQ_DK / NT, ERS = NT / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                          // [VQ_RB][XSTR]
   float* Es = smem + VQ_RB * a.XSTR;         // [VQ_CT][VQ_ES]
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_f32_kernel(ArgminArgs a) {
   const int D = a.D, K = a.K, XSTR = a.XSTR;
 
   // stage the stationary x block (zero padded to Dp columns / missing rows)
-  for (int e = tid; e < VQ_RB * a.Dp; e += 256) {
+  for (int e = tid; e < VQ_RB * a.Dp; e += NT) {
     const int r = e / a.Dp, d = e - r * a.Dp;
     const long row = r0 + r;
     Xs[r * XSTR + d] = (row < a.N && d < D) ? a.x[row * D + d] : 0.f;
@@ -76,19 +80,19 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_f32_kernel(ArgminArgs a) {
     bidx[r] = 0x7fffffff;
   }
 
-  // codebook staging: 128 codes x 32 dims = 4096 floats -> 16 per thread; thread -> (code = e/32, d = e%32)
-  const int ecol = tid & 31, erow0 = tid >> 5;  // rows erow0 + 8*i
-  float er[16];
+  // codebook staging: 128 codes x 32 dims = 4096 floats -> EPT per thread; thread -> (code = e/32, d = e%32)
+  const int ecol = tid & 31, erow0 = tid >> 5;  // rows erow0 + ERS*i
+  float er[EPT];
   auto load_e = [&](int k0, int d0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int k = k0 + erow0 + 8 * i, d = d0 + ecol;
+    for (int i = 0; i < EPT; ++i) {
+      const int k = k0 + erow0 + ERS * i, d = d0 + ecol;
       er[i] = (k < K && d < D) ? a.e[(long)k * D + d] : 0.f;
     }
   };
   auto store_e = [&]() {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Es[(erow0 + 8 * i) * VQ_ES + ecol] = er[i];
+    for (int i = 0; i < EPT; ++i) Es[(erow0 + ERS * i) * VQ_ES + ecol] = er[i];
   };
 
   const int nd = a.Dp / VQ_DK;
@@ -297,7 +301,7 @@ extern "C" int alvq_vq_argmin_f32(const float* x, const float* codebook, int64_t
   ALVQ_REQUIRE(x && codebook && idx && workspace, ALVQ_EINVAL, "alvq_vq_argmin_f32: null pointer");
   ALVQ_REQUIRE(N > 0 && K > 0 && D > 0, ALVQ_EINVAL, "alvq_vq_argmin_f32: bad dims N=%ld K=%d D=%d", (long)N, K, D);
   ALVQ_REQUIRE(D <= 512, ALVQ_EUNSUPPORTED, "alvq_vq_argmin_f32: D=%d > 512 does not fit the stationary LDS tile", D);
-  ALVQ_REQUIRE(N / VQ_RB < (1L << 31) - 2, ALVQ_EUNSUPPORTED, "alvq_vq_argmin_f32: N too large");
+  ALVQ_REQUIRE(N / 64 < (1L << 31) - 2, ALVQ_EUNSUPPORTED, "alvq_vq_argmin_f32: N too large");
   hipStream_t s = (hipStream_t)stream;
   float* xn = (float*)workspace;
   float* en = xn + N;
@@ -306,13 +310,19 @@ extern "C" int alvq_vq_argmin_f32(const float* x, const float* codebook, int64_t
   const int Dp = (D + VQ_DK - 1) / VQ_DK * VQ_DK;
   const int XSTR = vq_pad32(Dp, 2);
   ArgminArgs a{x, codebook, xn, en, idx, min_dist, (long)N, K, D, Dp, XSTR};
-  const size_t lds = (size_t)(VQ_RB * XSTR + VQ_CT * VQ_ES) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(vq_argmin_f32_kernel, dim3((unsigned)((N + VQ_RB - 1) / VQ_RB)), dim3(256), lds, s, a);
+  // 8 waves (128 rows) when the stationary block of a 4-wave workgroup would leave one wave per SIMD
+  const bool wide = D > 128 && (size_t)(128 * XSTR + VQ_CT * VQ_ES) * sizeof(float) <= 160 * 1024;
+  const int rb = wide ? 128 : 64;
+  const size_t lds = (size_t)(rb * XSTR + VQ_CT * VQ_ES) * sizeof(float);
+  const dim3 grid((unsigned)((N + rb - 1) / rb));
+  if (wide) hipLaunchKernelGGL(vq_argmin_f32_kernel<8>, grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL(vq_argmin_f32_kernel<4>, grid, dim3(256), lds, s, a);
   return check_launch("alvq_vq_argmin_f32");
 }
 
