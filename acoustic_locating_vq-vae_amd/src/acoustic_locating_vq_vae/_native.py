@@ -266,11 +266,12 @@ def vq_gather_loss(flat, codebook, idx, beta):
     return q_st, out
 
 
-def vq_backward(g, grad_loss, flat, codebook, idx, beta, want_dx=True, want_dE=True):
+def vq_backward(g, grad_loss, flat, codebook, idx, beta, want_dx=True, want_dE=True, dE_out=None):
+    """dE_out: accumulate the codebook gradient into this (K,D) tensor instead of a fresh zeroed one."""
     N, D = flat.shape
     K = codebook.shape[0]
     dx = torch.empty_like(flat) if want_dx else None
-    dE = torch.zeros_like(codebook) if want_dE else None
+    dE = (dE_out if dE_out is not None else torch.zeros_like(codebook)) if want_dE else None
     ws = _workspace(lib().alvq_vq_backward_workspace_bytes(K, D), flat.device).data_ptr() if want_dE else None
     _check(lib().alvq_vq_backward_f32(_ptr(g, name="g"), _ptr(grad_loss, name="grad_loss"), _ptr(flat, name="x"),
                                       _ptr(codebook, name="codebook"), _ptr(idx, torch.int64, "idx"), _ptr(dx), _ptr(dE),

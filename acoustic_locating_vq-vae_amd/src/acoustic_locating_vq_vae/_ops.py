@@ -44,6 +44,39 @@ def get_compute_dtype():
     return _DTYPE
 
 
+# ---------------------------------------------------------------------------------------------------
+# gradient sinks: train_step.FlatBuffers registers, per parameter, the slice of its flat gradient buffer.  A
+# weight-gradient launch then accumulates straight into that slice (the split reduction does dw += sum) and the
+# autograd node returns None for it -- no per-parameter temporary, no extra elementwise "grad += new" pass.
+# ---------------------------------------------------------------------------------------------------
+import weakref
+
+_GRAD_SINKS = weakref.WeakValueDictionary()
+
+
+def register_grad_sinks(params):
+    for p in params:
+        if p.grad is not None:
+            _GRAD_SINKS[p.data_ptr()] = p.grad
+
+
+def _sink(t):
+    return _GRAD_SINKS.get(t.data_ptr()) if (t is not None and len(_GRAD_SINKS)) else None
+
+
+def _wgrad(eng, dy, x, kw, layout, w, b=None, dw_prev=None):
+    """(dw, db) of one conv use.  Sinked tensors come back as None (already accumulated in place); otherwise dw is
+    accumulated onto ``dw_prev`` (shared residual weights) or freshly allocated."""
+    sw, sb = _sink(w), _sink(b)
+    if sw is not None and (b is None or sb is not None):
+        eng.wgrad(dy, x, kw, layout, want_bias=b is not None, dw_out=sw, dbias_out=sb, accumulate=True)
+        return None, None
+    if b is not None:
+        dw, db = eng.wgrad(dy, x, kw, layout, want_bias=True, dw_out=dw_prev, accumulate=dw_prev is not None)
+        return dw, db
+    return eng.wgrad(dy, x, kw, layout, dw_out=dw_prev, accumulate=dw_prev is not None), None
+
+
 def dense(x):
     """Materialise a strided input as dense (B,C,L) fp32 on the GPU (train_rir.py:45 hands over a permuted view)."""
     if x.dtype != torch.float32:
@@ -76,8 +109,9 @@ class _F32Engine:
     def conv(self, x, w, layout=OIK, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, out_f32=False):
         return N.conv1d(x, w, bias, skip1, skip2, mask, post, relu, layout)
 
-    def wgrad(self, dy, x, kw, layout, want_bias=False, dw_out=None):
-        return N.conv1d_wgrad(dy, x, kw, layout, want_bias=want_bias, dw_out=dw_out, accumulate=dw_out is not None)
+    def wgrad(self, dy, x, kw, layout, want_bias=False, dw_out=None, dbias_out=None, accumulate=False):
+        return N.conv1d_wgrad(dy, x, kw, layout, want_bias=want_bias, dw_out=dw_out, dbias_out=dbias_out,
+                              accumulate=accumulate)
 
     def relu_mask(self, dy, t):
         return N.relu_mask(dy, t)
@@ -112,8 +146,9 @@ class _BF16Engine:
     def conv(self, x, w, layout=OIK, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, out_f32=False):
         return N.conv1d_bf16(x, self._w(w, layout), bias, skip1, skip2, mask, post, relu, out_ncl=out_f32)
 
-    def wgrad(self, dy, x, kw, layout, want_bias=False, dw_out=None):
-        return N.conv1d_wgrad_bf16(dy, x, kw, layout, want_bias=want_bias, dw_out=dw_out, accumulate=dw_out is not None)
+    def wgrad(self, dy, x, kw, layout, want_bias=False, dw_out=None, dbias_out=None, accumulate=False):
+        return N.conv1d_wgrad_bf16(dy, x, kw, layout, want_bias=want_bias, dw_out=dw_out, dbias_out=dbias_out,
+                                   accumulate=accumulate)
 
     def relu_mask(self, dy, t):
         return N.relu_mask_bf16(dy, t)
@@ -178,8 +213,8 @@ def _stack_backward(eng, dh, ts, us, w1, w2, R, outer=None):
     dw1 = dw2 = None
     for r in range(R - 1, -1, -1):
         du = eng.conv(dh, w2, IOK, mask=us[r])                                 # k1 data-grad, * (u_r > 0)
-        dw2 = eng.wgrad(dh, us[r], 1, OIK, dw_out=dw2)
-        dw1 = eng.wgrad(du, ts[r], 3, OIK, dw_out=dw1)
+        dw2, _ = _wgrad(eng, dh, us[r], 1, OIK, w2, dw_prev=dw2)
+        dw1, _ = _wgrad(eng, du, ts[r], 3, OIK, w1, dw_prev=dw1)
         dh = eng.conv(du, w1, IOK, skip1=dh, skip2=outer if r == 0 else None, mask=ts[r])
     return dh, dw1, dw2
 
@@ -191,10 +226,10 @@ def _encoder_forward(eng, x, wc, bc, w1, w2, R):
     return xi, ts, us, out
 
 
-def _encoder_backward(eng, d_out, xi, ts, us, wc, w1, w2, R, need_dx):
+def _encoder_backward(eng, d_out, xi, ts, us, wc, bc, w1, w2, R, need_dx):
     dh = eng.relu_mask(d_out, ts[R])                                             # * (h_R > 0)
     dh0, dw1, dw2 = _stack_backward(eng, dh, ts, us, w1, w2, R, outer=d_out)
-    dwc, dbc = eng.wgrad(dh0, xi, 3, OIK, want_bias=True)
+    dwc, dbc = _wgrad(eng, dh0, xi, 3, OIK, wc, bc)
     dx = eng.conv(dh0, wc, IOK, out_f32=True) if need_dx else None
     return dx, dwc, dbc, dw1, dw2
 
@@ -207,15 +242,16 @@ class EncoderFn(torch.autograd.Function):
         eng = _engine()
         xi, ts, us, out = _encoder_forward(eng, x, wc, bc, w1, w2, R)
         ctx.R = R
-        _save(ctx, eng, (wc, w1, w2), [xi, *ts, *us])
+        _save(ctx, eng, (wc, bc, w1, w2), [xi, *ts, *us])
         return eng.leave(out)
 
     @staticmethod
     def backward(ctx, d_out):
         R = ctx.R
-        eng, (wc, w1, w2), acts = _load(ctx)
+        eng, (wc, bc, w1, w2), acts = _load(ctx)
         xi, ts, us = acts[0], acts[1:R + 2], acts[R + 2:]
-        dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, eng.enter(d_out), xi, ts, us, wc, w1, w2, R, ctx.needs_input_grad[0])
+        dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, eng.enter(d_out), xi, ts, us, wc, bc, w1, w2, R,
+                                                   ctx.needs_input_grad[0])
         return dx, dwc, dbc, dw1, dw2, None
 
 
@@ -229,18 +265,18 @@ class LatentFn(torch.autograd.Function):
         xi, ts, us, out = _encoder_forward(eng, x, wc, bc, w1, w2, R)
         z = eng.conv(out, wp, bias=bp, out_f32=True)
         ctx.R = R
-        _save(ctx, eng, (wc, w1, w2, wp), [xi, out, *ts, *us])
+        _save(ctx, eng, (wc, bc, w1, w2, wp, bp), [xi, out, *ts, *us])
         return z
 
     @staticmethod
     def backward(ctx, dz):
         R = ctx.R
-        eng, (wc, w1, w2, wp), acts = _load(ctx)
+        eng, (wc, bc, w1, w2, wp, bp), acts = _load(ctx)
         xi, out, ts, us = acts[0], acts[1], acts[2:R + 3], acts[R + 3:]
         dzi = eng.enter(dz)
         d_out = eng.conv(dzi, wp, IOK)
-        dwp, dbp = eng.wgrad(dzi, out, 3, OIK, want_bias=True)
-        dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, d_out, xi, ts, us, wc, w1, w2, R, ctx.needs_input_grad[0])
+        dwp, dbp = _wgrad(eng, dzi, out, 3, OIK, wp, bp)
+        dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, d_out, xi, ts, us, wc, bc, w1, w2, R, ctx.needs_input_grad[0])
         return dx, dwc, dbc, dw1, dw2, dwp, dbp, None
 
 
@@ -284,8 +320,8 @@ class ResidualLayerFn(torch.autograd.Function):
         eng, (w1, w2), (t, u) = _load(ctx)
         dyi = eng.enter(dy)
         du = eng.conv(dyi, w2, IOK, mask=u)
-        dw2 = eng.wgrad(dyi, u, 1, OIK)
-        dw1 = eng.wgrad(du, t, 3, OIK)
+        dw2, _ = _wgrad(eng, dyi, u, 1, OIK, w2)
+        dw1, _ = _wgrad(eng, du, t, 3, OIK, w1)
         dx = eng.conv(du, w1, IOK, skip1=dyi, mask=t)
         return eng.leave(dx), dw1, dw2
 
@@ -298,18 +334,17 @@ class ConvFn(torch.autograd.Function):
         eng = _engine()
         xi = eng.enter(x)
         ctx.layout = layout
-        _save(ctx, eng, (w,), [xi])
+        ctx.has_bias = b is not None
+        _save(ctx, eng, (w,) + ((b,) if b is not None else ()), [xi])
         return eng.conv(xi, w, layout, bias=b, out_f32=True)
 
     @staticmethod
     def backward(ctx, dy):
-        eng, (w,), (xi,) = _load(ctx)
+        eng, plain, (xi,) = _load(ctx)
+        w, b = plain[0], (plain[1] if ctx.has_bias else None)
         dyi = eng.enter(dy)
         kw = w.shape[2]
-        if ctx.needs_input_grad[2]:
-            dw, db = eng.wgrad(dyi, xi, kw, ctx.layout, want_bias=True)
-        else:
-            dw, db = eng.wgrad(dyi, xi, kw, ctx.layout), None
+        dw, db = _wgrad(eng, dyi, xi, kw, ctx.layout, w, b if ctx.needs_input_grad[2] else None)
         dx = eng.conv(dyi, w, IOK if ctx.layout == OIK else OIK, out_f32=True) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None
 
@@ -343,23 +378,23 @@ class DecoderFn(torch.autograd.Function):
         y = eng.conv(a2, wt3, IOK, bias=bt3, out_f32=True)
         ctx.R = R
         ctx.src = src
-        _save(ctx, eng, (wd, w1, w2, wt1, wt2, wt3), [qj, a1, a2, *ts, *us])
+        _save(ctx, eng, (wd, w1, w2, wt1, wt2, wt3, bd, bt1, bt2, bt3), [qj, a1, a2, *ts, *us])
         return y
 
     @staticmethod
     def backward(ctx, dy):
         R = ctx.R
-        eng, (wd, w1, w2, wt1, wt2, wt3), acts = _load(ctx)
+        eng, (wd, w1, w2, wt1, wt2, wt3, bd, bt1, bt2, bt3), acts = _load(ctx)
         qj, a1, a2, ts, us = acts[0], acts[1], acts[2], acts[3:R + 4], acts[R + 4:]
         dyi = eng.enter(dy)
         da2 = eng.conv(dyi, wt3, OIK, mask=a2)                                   # convT data-grad, * (a2 > 0)
-        dwt3, dbt3 = eng.wgrad(dyi, a2, 3, IOK, want_bias=True)
+        dwt3, dbt3 = _wgrad(eng, dyi, a2, 3, IOK, wt3, bt3)
         da1 = eng.conv(da2, wt2, OIK, mask=a1)
-        dwt2, dbt2 = eng.wgrad(da2, a1, 3, IOK, want_bias=True)
+        dwt2, dbt2 = _wgrad(eng, da2, a1, 3, IOK, wt2, bt2)
         dh = eng.conv(da1, wt1, OIK, mask=ts[R])                                 # * (h_R > 0)
-        dwt1, dbt1 = eng.wgrad(da1, ts[R], 3, IOK, want_bias=True)
+        dwt1, dbt1 = _wgrad(eng, da1, ts[R], 3, IOK, wt1, bt1)
         dh0, dw1, dw2 = _stack_backward(eng, dh, ts, us, w1, w2, R)
-        dwd, dbd = eng.wgrad(dh0, qj, 3, OIK, want_bias=True)
+        dwd, dbd = _wgrad(eng, dh0, qj, 3, OIK, wd, bd)
         dq = None
         if ctx.needs_input_grad[0]:
             dq = eng.conv(dh0, wd, IOK, out_f32=True)
@@ -391,11 +426,12 @@ class VQFn(torch.autograd.Function):
         if dloss is None:
             dloss = torch.zeros((), device=flat.device)
         want_de = ctx.train_vq and ctx.needs_input_grad[1]
+        sink = _sink(codebook) if want_de else None
         dx, dE = N.vq_backward(g, dloss.reshape(1).contiguous(), flat, codebook, idx, ctx.beta,
-                               want_dx=ctx.needs_input_grad[0], want_dE=want_de)
+                               want_dx=ctx.needs_input_grad[0], want_dE=want_de, dE_out=sink)
         if dx is not None:
             dx = dx.view(ctx.zshape)
-        return dx, dE, None, None
+        return dx, (None if sink is not None else dE), None, None
 
 
 class MSEFn(torch.autograd.Function):

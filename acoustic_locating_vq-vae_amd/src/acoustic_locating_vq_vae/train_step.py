@@ -140,6 +140,8 @@ class Trainer:
                 for p in m.parameters():
                     p.requires_grad_(False)   # only the decoder ever receives gradients (echoed_speech_model.py:53-54)
         self.buffers = FlatBuffers(params)
+        if self.buffers.flat.is_cuda:
+            _ops.register_grad_sinks(self.buffers.params)     # weight-grad launches accumulate straight into the flat buffer
         self.buffers.broadcast_params(group=group)
         self.opt = FlatAdam(self.buffers, lr=lr)
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
