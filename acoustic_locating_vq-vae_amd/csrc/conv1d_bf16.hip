@@ -396,16 +396,17 @@ __global__ __launch_bounds__(256) void bias_grad_nlc_partial_kernel(const u16* d
 // dbias[m] (+)= sum_s partial[s][m]; 64 channels x 4 split-phases per workgroup, fixed order.
 __global__ __launch_bounds__(256) void bias_grad_nlc_final_kernel(const float* partial, float* dbias, int splits, int Mp, int M,
                                                                   int accumulate) {
-  const int mi = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int m = blockIdx.x * 64 + mi;
+  // 32 channels x 8 split-phases per workgroup (coalesced along m, 8-way parallel along the splits), fixed order
+  const int mi = threadIdx.x & 31, ph = threadIdx.x >> 5;
+  const int m = blockIdx.x * 32 + mi;
   float s = 0.f;
   if (m < M)
-    for (int k = ph; k < splits; k += 4) s += partial[(long)k * Mp + m];
-  __shared__ float red[4][64];
+    for (int k = ph; k < splits; k += 8) s += partial[(long)k * Mp + m];
+  __shared__ float red[8][32];
   red[ph][mi] = s;
   __syncthreads();
   if (ph == 0 && m < M) {
-    const float t = (red[0][mi] + red[1][mi]) + (red[2][mi] + red[3][mi]);
+    const float t = ((red[0][mi] + red[1][mi]) + (red[2][mi] + red[3][mi])) + ((red[4][mi] + red[5][mi]) + (red[6][mi] + red[7][mi]));
     dbias[m] = accumulate ? dbias[m] + t : t;
   }
 }
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256) void relu_mask_bf16_kernel(const u16* dy, cons
   }
 }
 
-constexpr int BIAS_SPLITS = 512;   // row ranges of the bias-grad column sums (one workgroup each)
+constexpr int BIAS_SPLITS = 256;   // row ranges of the bias-grad column sums (one workgroup each)
 
 static int wgrad_b_splits(int total_rows, int M, int C, int* chunks_per_split) {
   const int nchunks = (total_rows + WG_R - 1) / WG_R;
@@ -579,7 +580,7 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
       float* bpart = (float*)((char*)workspace + wbytes);
       const int Mp = pad_to(M, TB_K), bs = BIAS_SPLITS, rps = (rows + bs - 1) / bs;
       hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
-      hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 63) / 64), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
+      hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 31) / 32), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
                          accumulate);
       rc = check_launch("alvq_conv1d_wgrad_bf16/bias");
     }
@@ -603,7 +604,7 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
     float* bpart = (float*)((char*)workspace + wbytes);
     const int Mp = pad_to(M, TB_K), bs = BIAS_SPLITS, rps = (rows + bs - 1) / bs;
     hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
-    hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 63) / 64), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
+    hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 31) / 32), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
                        accumulate);
     rc = check_launch("alvq_conv1d_wgrad_bf16/bias");
   }

@@ -496,17 +496,18 @@ __global__ __launch_bounds__(256) void bias_grad_x3_partial_kernel(const u16* dy
 }
 
 __global__ __launch_bounds__(256) void bias_grad_x3_final_kernel(const float* partial, float* dbias, int splits, int Mp, int M,
-                                                                 int accumulate) {
-  const int mi = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int m = blockIdx.x * 64 + mi;
+                                                                  int accumulate) {
+  // 32 channels x 8 split-phases per workgroup (coalesced along m, 8-way parallel along the splits), fixed order
+  const int mi = threadIdx.x & 31, ph = threadIdx.x >> 5;
+  const int m = blockIdx.x * 32 + mi;
   float s = 0.f;
   if (m < M)
-    for (int k = ph; k < splits; k += 4) s += partial[(long)k * Mp + m];
-  __shared__ float red[4][64];
+    for (int k = ph; k < splits; k += 8) s += partial[(long)k * Mp + m];
+  __shared__ float red[8][32];
   red[ph][mi] = s;
   __syncthreads();
   if (ph == 0 && m < M) {
-    const float t = (red[0][mi] + red[1][mi]) + (red[2][mi] + red[3][mi]);
+    const float t = ((red[0][mi] + red[1][mi]) + (red[2][mi] + red[3][mi])) + ((red[4][mi] + red[5][mi]) + (red[6][mi] + red[7][mi]));
     dbias[m] = accumulate ? dbias[m] + t : t;
   }
 }
@@ -527,7 +528,7 @@ static int wgrad_x3_splits(int total_rows, int tiles, int* chunks_per_split) {
   return (nchunks + cps - 1) / cps;
 }
 
-constexpr int X3_BIAS_SPLITS = 512;
+constexpr int X3_BIAS_SPLITS = 256;
 
 }  // namespace alvq
 
@@ -656,7 +657,7 @@ extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw
     const int Mp = pad_to(M, 64), bs = X3_BIAS_SPLITS, rps = (rows + bs - 1) / bs;
     hipLaunchKernelGGL(bias_grad_x3_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, a.dy_plane,
                        bpart, rows, Mp, rps);
-    hipLaunchKernelGGL(bias_grad_x3_final_kernel, dim3((M + 63) / 64), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
+    hipLaunchKernelGGL(bias_grad_x3_final_kernel, dim3((M + 31) / 32), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
                        accumulate);
     rc = check_launch("alvq_conv1d_wgrad_bf16x3/bias");
   }
