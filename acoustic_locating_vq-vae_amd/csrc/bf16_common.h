@@ -103,8 +103,8 @@ __device__ __forceinline__ void epilogue_store8(const ConvBArgs& a, float (&v)[8
 int conv1d_bf16_v2_launch(const ConvBArgs& a, int KW, hipStream_t stream);
 // defined in conv1d_wgrad_bf16_v2.hip: ring-pipelined weight-gradient (+ its fixed-order split reduction)
 int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int KW);
-int conv1d_wgrad_bf16_v2_launch(const void* dy, const void* x, float* dw, void* workspace, int total_rows, int C, int M,
-                                int KW, int w_layout, int accumulate, hipStream_t s);
+int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                int total_rows, int C, int M, int KW, int w_layout, int accumulate, hipStream_t s);
 
 
 }  // namespace alvq

@@ -574,7 +574,7 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
   const int64_t w2 = conv1d_wgrad_bf16_v2_workspace_bytes(rows, C, M, KW);
   if (w2 > wbytes) wbytes = w2;
   if (use_v2) {
-    int rc = conv1d_wgrad_bf16_v2_launch(dy, x, dw, workspace, rows, C, M, KW, w_layout, accumulate, s);
+    int rc = conv1d_wgrad_bf16_v2_launch(&dy, &x, 1, dw, workspace, rows, C, M, KW, w_layout, accumulate, s);
     if (rc) return rc;
     if (dbias) {
       float* bpart = (float*)((char*)workspace + wbytes);
@@ -609,4 +609,16 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
     rc = check_launch("alvq_conv1d_wgrad_bf16/bias");
   }
   return rc;
+}
+
+extern "C" int alvq_conv1d_wgrad_bf16_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                            int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream) {
+  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16_multi: null pointer");
+  ALVQ_REQUIRE(nseg >= 1 && nseg <= 4, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16_multi: nseg=%d (1..4)", nseg);
+  for (int i = 0; i < nseg; ++i) ALVQ_REQUIRE(dy[i] && x[i], ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16_multi: null segment %d", i);
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16_multi: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16_multi: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16_multi: w_layout");
+  return conv1d_wgrad_bf16_v2_launch(dy, x, nseg, dw, workspace, (int)alvq_nlc_rows(B, L), C, M, KW, w_layout, accumulate,
+                                     (hipStream_t)stream);
 }

@@ -24,12 +24,15 @@ namespace alvq {
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
+constexpr int WG_MAXSEG = 4;
 struct WgradV2Args {
-  const u16* dy;   // [rows][Mp]
-  const u16* x;    // [rows][Cp]
-  float* partial;  // [splits][KW][M][C]
+  // Up to WG_MAXSEG (dy, x) pairs of identical shape whose products are summed into ONE dW: the R uses of a shared
+  // residual weight (residual_stack.py:40-41) become a single longer contraction -- one split reduction instead of R.
+  const u16* dy[WG_MAXSEG];   // [rows][Mp]
+  const u16* x[WG_MAXSEG];    // [rows][Cp]
+  float* partial;             // [splits][KW][M][C]
   int Mp, Cp, M, C;
-  int mtiles, ctiles, splits, chunks_per_split, total_rows;
+  int mtiles, ctiles, splits, chunks_per_split, total_rows, nseg;
 };
 
 // Two transposing reads (rows r..r+3 and r+16..r+19 of one 16-column block) -> one 8-element k fragment.
@@ -74,8 +77,11 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
   const int id = xcd_remap(blockIdx.x, ntile * a.splits);
   const int split = id / ntile, t_id = id % ntile;
   const int m0 = (t_id / a.ctiles) * MT, c0 = (t_id % a.ctiles) * CT;
+  // rows are numbered through all segments: virtual row v = seg * total_rows + r (total_rows % 64 == 0, so neither a
+  // 64-row chunk nor a 32-row K-tile straddles two segments)
+  const int vrows = a.nseg * a.total_rows;
   const int rbeg = split * a.chunks_per_split * 64;
-  const int rend = min(a.total_rows, rbeg + a.chunks_per_split * 64);
+  const int rend = min(vrows, rbeg + a.chunks_per_split * 64);
   const int n = (rend - rbeg) / 32;                    // K-tiles in this split (even; may be 0)
 
   // ---- DMA: lane i of a 1-KB piece covers bytes [16i, 16i+16): row = 16i / RB, 16-B slot = (16i % RB) / 16.
@@ -85,13 +91,16 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
   auto src_slot = [](int slot, int row) { return (slot & 16) | (((((slot >> 1) & 7) ^ (row & 7)) << 1) | (slot & 1)); };
   const int last_row = a.total_rows - 1;
 
-  int is_row = rbeg;   // first row of the K-tile the next issue() stages
+  int is_seg = rbeg / a.total_rows;          // segment and first row (inside it) of the K-tile the next issue() stages
+  int is_row = rbeg - is_seg * a.total_rows;
   auto issue = [&](int stage) {
     unsigned char* dst = lds + stage * STAGE;
+    const u16* const dyp = a.dy[is_seg];
+    const u16* const xp = a.x[is_seg];
     {  // dY: piece = wave (rows 4*wave .. +3)
       const int lr = 4 * wave + y_r;
       const int mcol = min(m0 + src_slot(y_s, lr) * 8, a.Mp - 8);   // tiles past Mp re-read the last chunk (discarded)
-      glds16(a.dy + (long)(is_row + lr) * a.Mp + mcol, dst + wave * 1024);
+      glds16(dyp + (long)(is_row + lr) * a.Mp + mcol, dst + wave * 1024);
     }
 #pragma unroll
     for (int q = 0; q < (XPIECES + 7) / 8; ++q) {
@@ -101,10 +110,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
         int gr = is_row - PAD + lr;                                  // rows outside the matrix -> a zero row
         gr = gr < 0 ? 0 : (gr > last_row ? last_row : gr);
         const int ccol = min(c0 + src_slot(x_s, lr) * 8, a.Cp - 8);
-        glds16(a.x + (long)gr * a.Cp + ccol, dst + YBYTES + p * 1024);
+        glds16(xp + (long)gr * a.Cp + ccol, dst + YBYTES + p * 1024);
       }
     }
     is_row += 32;
+    if (is_row == a.total_rows) {
+      is_row = 0;
+      ++is_seg;
+    }
   };
   // glds issued per K-tile by THIS wave (for the counted waits)
   const bool extra = (XPIECES % 8 != 0) && (wave < XPIECES % 8);
@@ -263,16 +276,25 @@ int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int K
   const int ct = KW == 3 ? 128 : 256;
   const int tiles = ((M + 127) / 128) * ((C + ct - 1) / ct);
   int cps;
-  const int splits = wgrad_v2_splits(total_rows, tiles, &cps);
-  return (int64_t)splits * KW * M * C * 4;
+  const int splits = wgrad_v2_splits(WG_MAXSEG * total_rows, tiles, &cps);   // the split count never exceeds this
+  const int splits1 = wgrad_v2_splits(total_rows, tiles, &cps);
+  return (int64_t)(splits > splits1 ? splits : splits1) * KW * M * C * 4;
 }
 
-int conv1d_wgrad_bf16_v2_launch(const void* dy, const void* x, float* dw, void* workspace, int total_rows, int C, int M,
-                                int KW, int w_layout, int accumulate, hipStream_t s) {
+int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                int total_rows, int C, int M, int KW, int w_layout, int accumulate, hipStream_t s) {
   const int ct = KW == 3 ? 128 : 256;
   const int Mp = (M + 63) / 64 * 64, Cp = (C + 63) / 64 * 64;
-  WgradV2Args a{(const u16*)dy, (const u16*)x, (float*)workspace, Mp, Cp, M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, total_rows};
-  a.splits = wgrad_v2_splits(total_rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  WgradV2Args a{};
+  for (int i = 0; i < WG_MAXSEG; ++i) {
+    a.dy[i] = (const u16*)dy[i < nseg ? i : 0];
+    a.x[i] = (const u16*)x[i < nseg ? i : 0];
+  }
+  a.partial = (float*)workspace;
+  a.Mp = Mp; a.Cp = Cp; a.M = M; a.C = C;
+  a.mtiles = (M + 127) / 128; a.ctiles = (C + ct - 1) / ct;
+  a.total_rows = total_rows; a.nseg = nseg;
+  a.splits = wgrad_v2_splits(nseg * total_rows, a.mtiles * a.ctiles, &a.chunks_per_split);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<3, 2>());

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "alvq_conv1d_bf16": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p]),
     "alvq_conv1d_wgrad_bf16_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_bf16": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
+    "alvq_conv1d_wgrad_bf16_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p]),
     "alvq_nlc_plane_bytes": (_i64, [_i32, _i32, _i32]),
     "alvq_pack_weight_bf16x3": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_ncl_to_nlc_bf16x3": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
@@ -524,3 +525,28 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
                                           x.B, C, M, x.L, KW, w_layout, int(bool(accumulate)), _stream())
     _check(rc, "alvq_conv1d_wgrad_bf16")
     return (dw_out, dbias_out) if want_bias else dw_out
+
+
+def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=False):
+    """dw (+)= sum_i wgrad(dy_i, x_i) in one launch (shared residual weights).  pairs: [(dy NLC, x NLC), ...] (1..4)."""
+    dy0, x0 = pairs[0]
+    M, C = dy0.C, x0.C
+    for dy, x in pairs:
+        if (dy.B, dy.L, dy.C, dy.planes, x.B, x.L, x.C, x.planes) != (dy0.B, dy0.L, M, 1, x0.B, x0.L, C, 1):
+            raise RuntimeError("conv1d_wgrad_bf16_multi: all segments must share one shape (bf16, single plane)")
+    shape = (M, C, KW) if w_layout == W_OIK else (C, M, KW)
+    dev = x0.storage.device
+    if dw_out is None:
+        dw_out = torch.empty(shape, device=dev, dtype=torch.float32)
+        accumulate = False
+    elif tuple(dw_out.shape) != shape:
+        raise RuntimeError("conv1d_wgrad_bf16_multi: dw_out has shape %s, expected %s" % (tuple(dw_out.shape), shape))
+    n = len(pairs)
+    dys = (ctypes.c_void_p * n)(*[dy.ptr for dy, _ in pairs])
+    xs = (ctypes.c_void_p * n)(*[x.ptr for _, x in pairs])
+    ws = _workspace(lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x0.B, C, M, x0.L, KW), dev)
+    with _timed("conv1d_wgrad_bf16_v2_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):
+        rc = lib().alvq_conv1d_wgrad_bf16_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws.data_ptr(), x0.B, C, M, x0.L, KW,
+                                                w_layout, int(bool(accumulate)), _stream())
+    _check(rc, "alvq_conv1d_wgrad_bf16_multi")
+    return dw_out

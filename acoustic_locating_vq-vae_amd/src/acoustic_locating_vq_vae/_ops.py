@@ -153,6 +153,11 @@ class _BF16Engine:
     def relu_mask(self, dy, t):
         return N.relu_mask_bf16(dy, t)
 
+    @property
+    def wgrad_multi(self):
+        """sum_i wgrad(dy_i, x_i) in one launch -- plain bf16 only (the split mode loops)."""
+        return N.conv1d_wgrad_bf16_multi if self.planes == 1 else None
+
     def pack(self, act):
         return act.storage, (act.B, act.L, act.C, act.planes)
 
@@ -211,11 +216,22 @@ def _stack_backward(eng, dh, ts, us, w1, w2, R, outer=None):
     """dh = grad wrt h_R, already masked by (t_{R+1} > 0).  outer = extra grad flowing into t_1 (encoder skip).
     Returns (dh0 masked by t_1>0, dW1, dW2) with the R uses of the shared weights summed in a fixed order."""
     dw1 = dw2 = None
+    fused = getattr(eng, "wgrad_multi", None) is not None and 1 < R <= 4
+    pairs1, pairs2 = [], []
     for r in range(R - 1, -1, -1):
         du = eng.conv(dh, w2, IOK, mask=us[r])                                 # k1 data-grad, * (u_r > 0)
-        dw2, _ = _wgrad(eng, dh, us[r], 1, OIK, w2, dw_prev=dw2)
-        dw1, _ = _wgrad(eng, du, ts[r], 3, OIK, w1, dw_prev=dw1)
+        if fused:                                                              # one launch per shared weight, below
+            pairs2.append((dh, us[r]))
+            pairs1.append((du, ts[r]))
+        else:
+            dw2, _ = _wgrad(eng, dh, us[r], 1, OIK, w2, dw_prev=dw2)
+            dw1, _ = _wgrad(eng, du, ts[r], 3, OIK, w1, dw_prev=dw1)
         dh = eng.conv(du, w1, IOK, skip1=dh, skip2=outer if r == 0 else None, mask=ts[r])
+    if fused:
+        s1, s2 = _sink(w1), _sink(w2)
+        dw2 = eng.wgrad_multi(pairs2, 1, OIK, dw_out=s2, accumulate=s2 is not None)
+        dw1 = eng.wgrad_multi(pairs1, 3, OIK, dw_out=s1, accumulate=s1 is not None)
+        dw1, dw2 = (None if s1 is not None else dw1), (None if s2 is not None else dw2)
     return dh, dw1, dw2
 
 

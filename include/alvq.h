@@ -197,6 +197,13 @@ int64_t alvq_conv1d_wgrad_bf16_workspace_bytes(int B, int C, int M, int L, int K
 int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
                            int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
 
+/* The same weight gradient summed over nseg (1..4) operand pairs of identical shape in ONE launch:
+ * dw (+)= sum_i wgrad(dy[i], x[i]).  This is how the R uses of a shared residual weight (residual_stack.py:40-41)
+ * are accumulated: one longer contraction and one split reduction instead of R.  dy / x are HOST arrays of device
+ * pointers; no bias gradient (those layers have none).  Workspace: alvq_conv1d_wgrad_bf16_workspace_bytes. */
+int alvq_conv1d_wgrad_bf16_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                 int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
+
 /* ================================================================================================
  * Split-bf16 ("bf16x3") path: fp32-grade results on the bf16 matrix cores (gfx950 has no TF32/xf32 and its
  * exact-fp32 MFMA runs at 1/16 of the bf16 rate).  Every value is two bf16 planes, hi = bf16(v) and

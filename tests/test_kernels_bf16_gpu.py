@@ -101,3 +101,22 @@ def test_relu_mask_bf16():
     d, t = torch.randn(2, 70, 33), torch.randn(2, 70, 33)
     out = N.relu_mask_bf16(N.ncl_to_nlc(d.cuda()), N.ncl_to_nlc(t.cuda()))
     assert torch.equal(out.to_ncl().cpu(), torch.where(bf(t) > 0, bf(d), torch.zeros_like(d)))
+
+
+def test_wgrad_bf16_multi_segment_sums_uses():
+    """Shared residual weights: sum_i wgrad(dy_i, x_i) in one launch == the sum of the single launches."""
+    torch.manual_seed(6)
+    B, C, M, L = 2, 96, 160, 77
+    for KW in (1, 3):
+        pairs, want = [], 0
+        for _ in range(3):
+            x, dy = bf(torch.randn(B, C, L)), bf(torch.randn(B, M, L))
+            w = torch.zeros(M, C, KW, requires_grad=True)
+            F.conv1d(x, w, None, padding=KW // 2).backward(dy)
+            want = want + w.grad
+            pairs.append((N.ncl_to_nlc(dy.cuda()), N.ncl_to_nlc(x.cuda())))
+        got = N.conv1d_wgrad_bf16_multi(pairs, KW)
+        assert rel(got, want) < 3e-5
+        acc = N.conv1d_wgrad_bf16_multi(pairs[:2], KW, dw_out=got.clone(), accumulate=True)
+        single = N.conv1d_wgrad_bf16(pairs[0][0], pairs[0][1], KW) + N.conv1d_wgrad_bf16(pairs[1][0], pairs[1][1], KW)
+        assert rel(acc, got + single) < 3e-5
