@@ -61,10 +61,22 @@ struct ConvBArgs {
 constexpr int WP_ROWS = 256;   // packed weights are padded to this many rows per tap (largest m-tile)
 constexpr int NLC_ROW_PAD = 256;   // activation matrices are padded to this many rows (largest row tile)
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// two floats -> packed bf16 pair, round-to-nearest-even, by the gfx950 instruction v_cvt_pk_bf16_f32 (same bits as
+// f2bf for every finite input)
+__device__ __forceinline__ unsigned f2bf_pk(float lo, float hi) {
+  const f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+}
+
 // Fused epilogue for 8 consecutive output channels of one row (both conv kernels): v = acc (+bias) (+skip1)
 // (+skip2); relu; mask; y = bf16(v); y2 = bf16(v + post).  Gap / tail rows are written as zeros.
 __device__ __forceinline__ void epilogue_store8(const ConvBArgs& a, float (&v)[8], const float (&bv)[8], bool ok, long o) {
-  u16x8 out = {0, 0, 0, 0, 0, 0, 0, 0}, out2 = {0, 0, 0, 0, 0, 0, 0, 0};
+  u32x4 out = {0u, 0u, 0u, 0u}, out2 = {0u, 0u, 0u, 0u};
   if (ok) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += bv[e];
@@ -88,19 +100,21 @@ __device__ __forceinline__ void epilogue_store8(const ConvBArgs& a, float (&v)[8
       for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) out[e] = f2bf(v[e]);
+    for (int e = 0; e < 4; ++e) out[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
     if (a.y2) {
       const u16x8 s = *(const u16x8*)(a.post + o);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) out2[e] = f2bf(v[e] + bf2f(s[e]));
+      for (int e = 0; e < 4; ++e) out2[e] = f2bf_pk(v[2 * e] + bf2f(s[2 * e]), v[2 * e + 1] + bf2f(s[2 * e + 1]));
     }
   }
-  *(u16x8*)(a.y + o) = out;
-  if (a.y2) *(u16x8*)(a.y2 + o) = out2;
+  *(u32x4*)(a.y + o) = out;
+  if (a.y2) *(u32x4*)(a.y2 + o) = out2;
 }
 
 // defined in conv1d_bf16_v2.hip: the 256x256-tile kernel for wide layers
 int conv1d_bf16_v2_launch(const ConvBArgs& a, int KW, hipStream_t stream);
+// defined in conv1d_bf16_k3.hip: the same tile for width 3, one activation slab shared by the three taps
+int conv1d_bf16_k3_launch(const ConvBArgs& a, hipStream_t stream);
 // defined in conv1d_wgrad_bf16_v2.hip: ring-pipelined weight-gradient (+ its fixed-order split reduction)
 int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int KW);
 int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,

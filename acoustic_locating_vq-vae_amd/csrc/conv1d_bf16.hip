@@ -513,7 +513,9 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
   if (use_v2 < 0) use_v2 = getenv("ALVQ_CONV_V2") ? atoi(getenv("ALVQ_CONV_V2")) : 1;
   // wide layers: 256x256 tiles (v2) whenever the 256-wide m-tile is (nearly) full; narrow or ragged M
   // (128, 192, 201, 64, 1) stays on 128x128 tiles, which waste less there and give more workgroups.
-  if (use_v2 && pad_to(M, 256) - M <= 32) return conv1d_bf16_v2_launch(a, KW, s);
+  static int use_k3 = -1;
+  if (use_k3 < 0) use_k3 = getenv("ALVQ_CONV_K3") ? atoi(getenv("ALVQ_CONV_K3")) : 1;
+  if (use_v2 && pad_to(M, 256) - M <= 32) return (KW == 3 && use_k3) ? conv1d_bf16_k3_launch(a, s) : conv1d_bf16_v2_launch(a, KW, s);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

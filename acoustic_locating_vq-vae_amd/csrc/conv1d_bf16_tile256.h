@@ -1,0 +1,118 @@
+// Pieces shared by the two 256 x 256-tile bf16 convolution kernels (conv1d_bf16_v2.hip: any filter width, K-tile =
+// one tap; conv1d_bf16_k3.hip: width 3 with the activation slab shared by the three taps): tile constants, the
+// fragment register set and the fused epilogue.
+#pragma once
+#include "bf16_common.h"
+
+namespace alvq {
+
+constexpr int V2_M = 256, V2_R = 256, V2_K = 32;
+constexpr int V2_HALF = V2_M * V2_K * 2;          // 16384 B: one operand slab
+constexpr int V2_CS = V2_M + 4;                   // fp32 C-slab row stride (floats)
+constexpr int V2_EPI_LDS = 64 * V2_CS * 4;        // 66560 B of LDS used by the epilogue
+
+struct FragSet {
+  bf16x8_t a[8];
+  bf16x8_t b[4];
+};
+
+// Epilogue of a 256 x 256 tile held as 8 x 4 MFMA fragments per wave (wave w: out-channels (w>>2)*128.., rows
+// (w&3)*64..); D[i = m][j = row], so lane (li, kq) of fragment (mi, ni) holds channels mi*16 + kq*4 .. +3 of row
+// ni*16 + li.
+//   OUT == 0 (bf16 NLC): stored straight from the registers.  v_permlane16_swap between the fragments mi and mi+1
+//     first gives every lane 8 consecutive channels (lanes kq = 0, 2: channels (kq/2)*8.. of fragment mi; kq = 1, 3:
+//     of fragment mi+1), so loads and stores are 16 bytes per lane, the four lanes of a row cover 64 contiguous
+//     bytes and the next fragment pair completes the 128-byte line.  No LDS round trip, no barriers, and the
+//     skip / mask / post loads of different fragments are independent (they overlap instead of queueing behind one
+//     another).  The previous version transposed through LDS; its ~3000 VALU instructions per thread (software
+//     bf16 rounding, per-pass row decoding) made the epilogue 30 k cycles per tile -- 17 % of a width-3 tile's
+//     time, 37 % of a width-1 tile's.
+//   OUT == 1 (fp32 NCL, bias only; rare at this tile size): four 64-row slabs through an fp32 LDS tile so that lanes
+//     run along l.  All waves must have finished reading the operand stages before the call.
+template <int OUT>
+__device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4 (&acc)[8][4], unsigned char* lds, int m0,
+                                                 int r0, int wave, int tid, int li, int kq, int wm0) {
+  if (OUT == 0) {
+    const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+    const int wn0 = (wave & 3) * 64;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int row = r0 + wn0 + ni * 16 + li;
+      int b, l;
+      const bool ok = row_valid(row, Lp1, ndata, &b, &l);
+      const long ro = (long)row * a.Mop;
+#pragma unroll
+      for (int mp = 0; mp < 8; mp += 2) {
+        if (m0 + wm0 + mp * 16 >= a.Mop) continue;      // Mop % 64 == 0 and the pair starts on a multiple of 32
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // odd rows (of 16 lanes) of the first operand <-> even rows of the second
+          const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mp][ni][e]), __float_as_uint(acc[mp + 1][ni][e]),
+                                                           false, false);
+          v[e] = __uint_as_float(r[0]);
+          v[e + 4] = __uint_as_float(r[1]);
+        }
+        const int mb = m0 + wm0 + (mp + (kq & 1)) * 16 + (kq >> 1) * 8;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && mb + e < a.M) ? a.bias[mb + e] : 0.f;
+        epilogue_store8(a, v, bv, ok, ro + mb);
+      }
+    }
+    return;
+  }
+  float* Cs = (float*)lds;
+  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  for (int slab = 0; slab < 4; ++slab) {
+    if ((wave & 3) == slab) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int rl = ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
+          *(f32x4*)(Cs + rl * V2_CS + ml) = acc[mi][ni];
+        }
+    }
+    __syncthreads();
+    if (OUT == 0) {
+      // thread = 8 consecutive channels of one row; 32 threads per row, 16 rows per pass, 4 passes
+      const int tx = tid & 31, ty = tid >> 5;
+      const int mbase = m0 + tx * 8;
+      if (mbase < a.Mop) {
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && mbase + e < a.M) ? a.bias[mbase + e] : 0.f;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int rl = pass * 16 + ty, row = r0 + slab * 64 + rl;
+          int b, l;
+          const bool ok = row_valid(row, Lp1, ndata, &b, &l);
+          const long o = (long)row * a.Mop + mbase;
+          float v[8];
+          const f32x4 c0 = *(const f32x4*)(Cs + rl * V2_CS + tx * 8), c1 = *(const f32x4*)(Cs + rl * V2_CS + tx * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = c0[e];
+            v[e + 4] = c1[e];
+          }
+          epilogue_store8(a, v, bv, ok, o);
+        }
+      }
+    } else {
+      // NCL fp32 (bias only): lane = row (coalesced along l), loop over channels
+      const int rl = tid & 63, row = r0 + slab * 64 + rl;
+      int b, l;
+      if (row_valid(row, Lp1, ndata, &b, &l)) {
+        for (int ml = tid >> 6; ml < V2_M; ml += 8) {
+          const int m = m0 + ml;
+          if (m >= a.M) break;
+          a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * V2_CS + ml] + (a.bias ? a.bias[m] : 0.f);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace alvq

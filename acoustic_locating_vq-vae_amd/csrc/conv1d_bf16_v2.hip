@@ -21,21 +21,14 @@
 
 #include "alvq_common.h"
 #include "bf16_common.h"
+#include "conv1d_bf16_tile256.h"
 
 namespace alvq {
 
-constexpr int V2_M = 256, V2_R = 256, V2_K = 32;
-constexpr int V2_HALF = V2_M * V2_K * 2;          // 16384 B: one operand slab
 constexpr int V2_STAGE = 2 * V2_HALF;             // 32768 B
 constexpr int V2_NSTAGE = 4;
 constexpr int V2_LDS = V2_NSTAGE * V2_STAGE;      // 131072 B
-constexpr int V2_CS = V2_M + 4;                   // fp32 C-slab row stride (floats)
-static_assert(64 * V2_CS * 4 <= V2_LDS, "C slab must fit");
-
-struct FragSet {
-  bf16x8_t a[8];
-  bf16x8_t b[4];
-};
+static_assert(V2_EPI_LDS <= V2_LDS, "C slab must fit");
 
 // DBG (timing experiments; 1-3 give wrong results): 1 = no DMA in the loop, 2 = no vmcnt waits, 3 = no barriers,
 // 4 = no issue stagger (correct results)
@@ -173,58 +166,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
     __syncthreads();
   }
 
-  // ---- epilogue: four 64-row slabs through an fp32 LDS tile; D[i = m][j = row]
-  float* Cs = (float*)lds;
-  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
-  for (int slab = 0; slab < 4; ++slab) {
-    if ((wave & 3) == slab) {
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int rl = ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
-          *(f32x4*)(Cs + rl * V2_CS + ml) = acc[mi][ni];
-        }
-    }
-    __syncthreads();
-    if (OUT == 0) {
-      // thread = 8 consecutive channels of one row; 32 threads per row, 16 rows per pass, 4 passes
-      const int tx = tid & 31, ty = tid >> 5;
-      const int mbase = m0 + tx * 8;
-      if (mbase < a.Mop) {
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && mbase + e < a.M) ? a.bias[mbase + e] : 0.f;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int rl = pass * 16 + ty, row = r0 + slab * 64 + rl;
-          int b, l;
-          const bool ok = row_valid(row, Lp1, ndata, &b, &l);
-          const long o = (long)row * a.Mop + mbase;
-          float v[8];
-          const f32x4 c0 = *(const f32x4*)(Cs + rl * V2_CS + tx * 8), c1 = *(const f32x4*)(Cs + rl * V2_CS + tx * 8 + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = c0[e];
-            v[e + 4] = c1[e];
-          }
-          epilogue_store8(a, v, bv, ok, o);
-        }
-      }
-    } else {
-      // NCL fp32 (bias only): lane = row (coalesced along l), loop over channels
-      const int rl = tid & 63, row = r0 + slab * 64 + rl;
-      int b, l;
-      if (row_valid(row, Lp1, ndata, &b, &l)) {
-        for (int ml = tid >> 6; ml < V2_M; ml += 8) {
-          const int m = m0 + ml;
-          if (m >= a.M) break;
-          a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * V2_CS + ml] + (a.bias ? a.bias[m] : 0.f);
-        }
-      }
-    }
-    __syncthreads();
-  }
+  tile256_epilogue<OUT>(a, acc, lds, m0, r0, wave, tid, li, kq, wm0);
 }
 
 int conv1d_bf16_v2_launch(const ConvBArgs& a_in, int KW, hipStream_t stream) {

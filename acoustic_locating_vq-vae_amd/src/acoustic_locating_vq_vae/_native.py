@@ -486,7 +486,9 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     if split:
         family, fn = "conv1d_bf16x3_kernel", lib().alvq_conv1d_bf16x3
     else:
-        family = "conv1d_bf16_v2_kernel" if ((M + 255) // 256 * 256 - M) <= 32 else "conv1d_bf16_kernel"
+        # mirrors the dispatch in csrc/conv1d_bf16.hip: wide layers go to the 256x256-tile kernels (k3 for width 3)
+        wide = ((M + 255) // 256 * 256 - M) <= 32
+        family = ("conv1d_bf16_k3_kernel" if KW == 3 else "conv1d_bf16_v2_kernel") if wide else "conv1d_bf16_kernel"
         fn = lib().alvq_conv1d_bf16
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
         rc = fn(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),

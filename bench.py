@@ -29,7 +29,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 matrix rate 
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (NOT the 2:1-sparsity headline)
 PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS}
 CONV_FAMILIES = {"f32": ("conv1d_f32_kernel", "conv1d_wgrad_f32_kernel"),
-                 "bf16": ("conv1d_bf16_v2_kernel", "conv1d_bf16_kernel", "conv1d_wgrad_bf16_v2_kernel"),
+                 "bf16": ("conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel", "conv1d_wgrad_bf16_v2_kernel"),
                  "bf16x3": ("conv1d_bf16x3_kernel", "conv1d_wgrad_bf16x3_kernel")}
 SPEECH_CFG = (201, 1024, 128, 3, 1024, 0.25, 1024)          # scripts/train_speech.py:152-153
 RIR_CFG = (500, 1024, 64, 2, 64, 0.25, 1024)                # scripts/train_rir.py:147-149
@@ -98,10 +98,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # ALVQ_BENCH_BACKEND=gloo rehearses the N>1 control flow with several ranks sharing one card (RCCL refuses
+    # two ranks on one device); the driver's runs use the default: one rank per GPU over RCCL.
+    backend = os.environ.get("ALVQ_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from acoustic_locating_vq_vae import _native as N
     from acoustic_locating_vq_vae import _ops

@@ -1,5 +1,6 @@
 """Condense rocprofv3 output (gpurun_out/prof_*) into the small summaries committed under profiles/.
 
+    tools/profile_bench.sh bf16            # on the GPU box: writes gpurun_out/prof_bf16/{stats,fetch,write}
     python profiles/summarize.py <tag> <stats_dir> <fetch_dir> <write_dir>
 
 Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, alvq kernels + top others),
@@ -51,7 +52,10 @@ def main(tag, stats_dir, fetch_dir, write_dir):
         a[0] += f[0]; a[1] += f[1]; a[2] += wr[0]; a[3] += wr[1]
     json.dump(per_kernel, open(os.path.join(HERE, tag + "_pmc.json"), "w"), indent=1)
     traffic = {k: (2.0 * v[1] / max(v[0], 1) + v[3] / max(v[2], 1)) * 1024.0 for k, v in fam.items()}
-    json.dump(traffic, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
+    tpath = os.path.join(HERE, "traffic.json")                      # merged: each dtype contributes its own families
+    merged = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    merged.update(traffic)
+    json.dump(merged, open(tpath, "w"), indent=1, sort_keys=True)
     durs = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
         f = family(r["Name"])

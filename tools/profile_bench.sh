@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence committed under profiles/ (run on the GPU box from the repo root):
+#   tools/profile_bench.sh <dtype> [extra bench.py flags]
+# Three separate passes, as MI355X_MICROARCH.md prescribes: kernel trace + stats, then one --pmc pass per counter.
+set -e
+DT=${1:-bf16}; shift || true
+R=$PWD
+OUT=$R/gpurun_out/prof_$DT
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+FLAGS="--dtype $DT --steps 10 --warmup 3 --no-cpu-baseline --no-f32-line $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r01 -- python3 $R/bench.py $FLAGS > $OUT/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r01 -- python3 $R/bench.py $FLAGS --no-graph --no-kernel-timer > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o r01 -- python3 $R/bench.py $FLAGS --no-graph --no-kernel-timer > $OUT/bench_write.log 2>&1
+cd $R
+grep '^{' $OUT/bench_stats.log | tail -1 > $OUT/bench_under_rocprof.json
+# keep only what summarize.py reads (the traces themselves are large)
+find $OUT -name '*kernel_trace.csv' -delete
+ls -la $OUT/*
