@@ -595,11 +595,7 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
   else hipLaunchKernelGGL((conv1d_wgrad_bf16_kernel<1>), dim3(grid), dim3(256), 0, s, a);
   int rc = check_launch("alvq_conv1d_wgrad_bf16");
   if (rc) return rc;
-  const long total = (long)KW * M * C;
-  int rgrid = (int)((total + 255) / 256);
-  if (rgrid > 2048) rgrid = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, splits, KW, M, C, w_layout,
-                     accumulate);
+  wgrad_reduce_launch((const float*)workspace, dw, splits, KW, M, C, w_layout, accumulate, s);
   rc = check_launch("alvq_conv1d_wgrad_bf16/reduce");
   if (rc) return rc;
   if (dbias) {

@@ -429,11 +429,7 @@ extern "C" int alvq_conv1d_wgrad_f32(const float* dy, const float* x, float* dw,
     hipLaunchKernelGGL((conv1d_wgrad_f32_kernel<1>), dim3(grid), dim3(256), 0, s, a);
   int rc = check_launch("alvq_conv1d_wgrad_f32");
   if (rc) return rc;
-  const long total = (long)KW * M * C;
-  int rgrid = (int)((total + 255) / 256);
-  if (rgrid > 2048) rgrid = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)workspace, dw, splits, KW, M, C,
-                     w_layout, accumulate);
+  wgrad_reduce_launch((const float*)workspace, dw, splits, KW, M, C, w_layout, accumulate, s);
   rc = check_launch("alvq_conv1d_wgrad_f32/reduce");
   if (rc) return rc;
   if (dbias) {

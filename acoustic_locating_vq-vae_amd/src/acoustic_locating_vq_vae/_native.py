@@ -55,6 +55,7 @@ _SIGNATURES = {
     "alvq_nlc_guard_rows": (_i32, []),
     "alvq_packed_weight_elems": (_i64, [_i32, _i32, _i32]),
     "alvq_pack_weight_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_pack_weights_bf16_batch": (_i32, [_c_void_p, _i32, _i32, _c_void_p]),
     "alvq_ncl_to_nlc_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_nlc_to_ncl_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_relu_mask_bf16": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
@@ -453,6 +454,40 @@ def pack_weight(w, w_layout, planes=1):
     else:
         _check(lib().alvq_pack_weight_bf16(_ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout, _stream()), "alvq_pack_weight_bf16")
     return wp, (M, C, KW, planes)
+
+
+class PackDesc(ctypes.Structure):
+    """struct alvq_pack_desc (include/alvq.h)"""
+    _fields_ = [("w", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("M", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("KW", ctypes.c_int32), ("w_layout", ctypes.c_int32)]
+
+
+def packed_weight_alloc(w, w_layout, planes=1):
+    """Uninitialised packed image(s) for ``w`` + the (M, C, KW, planes) tag ``pack_weight`` returns."""
+    if w_layout == W_OIK:
+        M, C, KW = w.shape
+    else:
+        C, M, KW = w.shape
+    n = lib().alvq_packed_weight_elems(M, C, KW)
+    return torch.empty((planes * n,), device=w.device, dtype=torch.bfloat16), (M, C, KW, planes)
+
+
+def pack_weights_batch(entries, planes=1):
+    """entries: [(w fp32 cuda tensor, packed image from packed_weight_alloc, w_layout)] -- one launch for all."""
+    if not entries:
+        return
+    arr = (PackDesc * len(entries))()
+    for d, (w, wp, w_layout) in zip(arr, entries):
+        if w_layout == W_OIK:
+            M, C, KW = w.shape
+        else:
+            C, M, KW = w.shape
+        need = planes * lib().alvq_packed_weight_elems(M, C, KW)
+        if wp.numel() != need or wp.dtype != torch.bfloat16:
+            raise RuntimeError("pack_weights_batch: packed image has %d elements, expected %d" % (wp.numel(), need))
+        d.w, d.wp, d.M, d.C, d.KW, d.w_layout = _ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout
+    _check(lib().alvq_pack_weights_bf16_batch(ctypes.addressof(arr), len(entries), planes, _stream()),
+           "alvq_pack_weights_bf16_batch")
 
 
 def relu_mask_bf16(dy, t):

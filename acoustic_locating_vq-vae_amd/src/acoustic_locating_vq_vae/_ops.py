@@ -64,6 +64,60 @@ def _sink(t):
     return _GRAD_SINKS.get(t.data_ptr()) if (t is not None and len(_GRAD_SINKS)) else None
 
 
+# ---------------------------------------------------------------------------------------------------
+# packed-weight pool: inside a train step (train_step.Trainer._body) the bf16 engines do not re-pack a parameter
+# every time a layer uses it.  The pool keeps one persistent packed image per (parameter, layout); the trainer
+# refreshes all of them with ONE batched launch at the start of the step (after the previous optimiser update) and
+# the engines just look them up.  Outside a trainer step the pool is inactive and every use packs for itself, so
+# a model evaluated after training never sees a stale image.
+# ---------------------------------------------------------------------------------------------------
+class PackPool:
+    def __init__(self, params):
+        self._eligible = {p.data_ptr(): p for p in params if p.dim() == 3}
+        self._entries = {}          # (data_ptr, layout, planes) -> (packed image, tag)
+
+    def lookup(self, w, layout, planes):
+        key = (w.data_ptr(), layout, planes)
+        hit = self._entries.get(key)
+        if hit is not None:
+            return hit
+        p = self._eligible.get(key[0])
+        if p is None or p.shape != w.shape:
+            return None
+        # first use: allocate the persistent image and fill it now; later steps refresh it in the batched launch
+        img, tag = N.packed_weight_alloc(p.detach(), layout, planes)
+        N.pack_weights_batch([(p.detach(), img, layout)], planes)
+        self._entries[key] = (img, tag)
+        return self._entries[key]
+
+    def refresh(self):
+        by_planes = {}
+        for (ptr, layout, planes), (img, _) in self._entries.items():
+            by_planes.setdefault(planes, []).append((self._eligible[ptr].detach(), img, layout))
+        for planes, entries in by_planes.items():
+            N.pack_weights_batch(entries, planes)
+
+
+_ACTIVE_POOL = None
+
+
+class use_pack_pool:
+    """with use_pack_pool(pool): ...  -- the body of a trainer step"""
+
+    def __init__(self, pool):
+        self.pool = pool
+
+    def __enter__(self):
+        global _ACTIVE_POOL
+        self.prev, _ACTIVE_POOL = _ACTIVE_POOL, self.pool
+        if self.pool is not None:
+            self.pool.refresh()
+
+    def __exit__(self, *exc):
+        global _ACTIVE_POOL
+        _ACTIVE_POOL = self.prev
+
+
 def _wgrad(eng, dy, x, kw, layout, w, b=None, dw_prev=None):
     """(dw, db) of one conv use.  Sinked tensors come back as None (already accumulated in place); otherwise dw is
     accumulated onto ``dw_prev`` (shared residual weights) or freshly allocated."""
@@ -131,6 +185,10 @@ class _BF16Engine:
         self._packed = {}
 
     def _w(self, w, layout):
+        if _ACTIVE_POOL is not None:
+            hit = _ACTIVE_POOL.lookup(w, layout, self.planes)
+            if hit is not None:
+                return hit
         key = (w.data_ptr(), layout)
         pk = self._packed.get(key)
         if pk is None:

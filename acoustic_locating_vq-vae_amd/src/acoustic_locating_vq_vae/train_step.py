@@ -16,6 +16,8 @@ losses is the global mean, including the VQ terms.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -142,6 +144,10 @@ class Trainer:
         self.buffers = FlatBuffers(params)
         if self.buffers.flat.is_cuda:
             _ops.register_grad_sinks(self.buffers.params)     # weight-grad launches accumulate straight into the flat buffer
+        # every conv weight of the model (frozen sub-models of the echoed config included) keeps persistent packed
+        # bf16 images, refreshed by one launch per step
+        use_pool = self.buffers.flat.is_cuda and os.environ.get("ALVQ_PACK_POOL", "1") != "0"
+        self.pack_pool = _ops.PackPool(list(model.parameters())) if use_pool else None
         self.buffers.broadcast_params(group=group)
         self.opt = FlatAdam(self.buffers, lr=lr)
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -173,10 +179,11 @@ class Trainer:
         """Preprocess + forward + backward: the launch-bound part of a step (~150 launches) that a hipGraph
         captures.  The collective and the optimiser launch stay outside (``_finish``) so no RCCL call is ever
         recorded into a graph."""
-        x, target = self.preprocess(raw, wiener)
-        self.buffers.zero_grad()
-        loss, recon_error, perplexity = self.forward_loss(x, target)
-        loss.backward()
+        with _ops.use_pack_pool(self.pack_pool):            # one batched re-pack of every conv weight, then lookups
+            x, target = self.preprocess(raw, wiener)
+            self.buffers.zero_grad()
+            loss, recon_error, perplexity = self.forward_loss(x, target)
+            loss.backward()
         return loss.detach(), recon_error.detach(), perplexity.detach()
 
     def _finish(self):

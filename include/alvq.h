@@ -176,6 +176,17 @@ int alvq_nlc_guard_rows(void);
 int64_t alvq_packed_weight_elems(int M, int C, int KW);
 int alvq_pack_weight_bf16(const float* w, void* wp, int M, int C, int KW, int w_layout, void* stream);
 
+/* The same for n weights in one launch (a train step re-packs every conv weight, in the forward and in the
+ * data-gradient layout, after each optimiser update: one launch instead of ~20).  `descs` is a HOST array; it is
+ * copied into the kernel argument, so the call can be captured into a hipGraph.  planes = 1: bf16 images;
+ * planes = 2: the hi + lo images of the split-bf16 path (as alvq_pack_weight_bf16x3). */
+typedef struct alvq_pack_desc {
+  const float* w;   /* fp32 weight, (M,C,KW) for ALVQ_W_OIK or (C,M,KW) for ALVQ_W_IOK */
+  void* wp;         /* packed image(s): planes * alvq_packed_weight_elems(M,C,KW) bf16 values */
+  int32_t M, C, KW, w_layout;
+} alvq_pack_desc;
+int alvq_pack_weights_bf16_batch(const alvq_pack_desc* descs, int n, int planes, void* stream);
+
 /* (B,C,L) fp32 -> NLC-padded bf16 (the boundary conversion for x, quantized and incoming gradients). */
 int alvq_ncl_to_nlc_bf16(const float* x, void* y, int B, int C, int L, void* stream);
 

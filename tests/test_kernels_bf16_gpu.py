@@ -120,3 +120,24 @@ def test_wgrad_bf16_multi_segment_sums_uses():
         acc = N.conv1d_wgrad_bf16_multi(pairs[:2], KW, dw_out=got.clone(), accumulate=True)
         single = N.conv1d_wgrad_bf16(pairs[0][0], pairs[0][1], KW) + N.conv1d_wgrad_bf16(pairs[1][0], pairs[1][1], KW)
         assert rel(acc, got + single) < 3e-5
+
+
+@pytest.mark.parametrize("planes", [1, 2])
+def test_pack_weights_batch_matches_single_packs(planes):
+    """One batched launch (alvq_pack_weights_bf16_batch) == the per-weight packs, bit for bit: both layouts, widths 1
+    and 3, ragged M / C (zero padding included), more descriptors than one launch holds (32)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [(1024, 201, 3), (128, 1024, 1), (201, 1024, 3), (64, 64, 1), (33, 70, 3), (256, 128, 3), (1, 1024, 1)]
+    entries, singles = [], []
+    for rep in range(3):                                  # 7 shapes x 2 layouts x 3 = 42 descriptors
+        for (M, C, KW) in shapes:
+            for layout in (N.W_OIK, N.W_IOK):
+                w = torch.randn((M, C, KW) if layout == N.W_OIK else (C, M, KW), device="cuda", generator=g)
+                img, tag = N.packed_weight_alloc(w, layout, planes)
+                img.fill_(float("nan"))                   # every element must be written, padding included
+                entries.append((w, img, layout))
+                singles.append(N.pack_weight(w, layout, planes))
+    N.pack_weights_batch(entries, planes)
+    for (w, img, layout), (ref, tag) in zip(entries, singles):
+        assert tag[3] == planes
+        assert torch.equal(img.view(torch.int16), ref.view(torch.int16)), (tuple(w.shape), layout)
