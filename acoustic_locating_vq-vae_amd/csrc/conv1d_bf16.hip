@@ -576,17 +576,9 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
   const int64_t w2 = conv1d_wgrad_bf16_v2_workspace_bytes(rows, C, M, KW);
   if (w2 > wbytes) wbytes = w2;
   if (use_v2) {
-    int rc = conv1d_wgrad_bf16_v2_launch(&dy, &x, 1, dw, workspace, rows, C, M, KW, w_layout, accumulate, s);
-    if (rc) return rc;
-    if (dbias) {
-      float* bpart = (float*)((char*)workspace + wbytes);
-      const int Mp = pad_to(M, TB_K), bs = BIAS_SPLITS, rps = (rows + bs - 1) / bs;
-      hipLaunchKernelGGL(bias_grad_nlc_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, bpart, rows, Mp, rps);
-      hipLaunchKernelGGL(bias_grad_nlc_final_kernel, dim3((M + 31) / 32), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
-                         accumulate);
-      rc = check_launch("alvq_conv1d_wgrad_bf16/bias");
-    }
-    return rc;
+    // the bias gradient rides in the same launch (column sums of dY by an all-ones MFMA operand)
+    return conv1d_wgrad_bf16_v2_launch(&dy, &x, 1, dw, workspace, rows, C, M, KW, w_layout, accumulate, s, dbias,
+                                       (float*)((char*)workspace + wbytes));
   }
   WgradBArgs a{(const u16*)dy, (const u16*)x, (float*)workspace, pad_to(M, TB_K), pad_to(C, TB_K), M, C,
                (M + WG_M - 1) / WG_M, (C + WG_C - 1) / WG_C, splits, cps, rows};

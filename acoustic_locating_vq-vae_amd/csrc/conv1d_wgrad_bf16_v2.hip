@@ -31,6 +31,7 @@ struct WgradV2Args {
   const u16* dy[WG_MAXSEG];   // [rows][Mp]
   const u16* x[WG_MAXSEG];    // [rows][Cp]
   float* partial;             // [splits][KW][M][C]
+  float* bias_partial;        // [splits][Mp] column sums of dY (the bias gradient), or null
   int Mp, Cp, M, C;
   int mtiles, ctiles, splits, chunks_per_split, total_rows, nseg;
 };
@@ -177,6 +178,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NCF; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Bias gradient = column sums of dY: the workgroups of c-tile 0 multiply their dY fragments by an all-ones
+  // operand as well (one wave per 64 m; 4 extra MFMAs per K-tile), instead of a separate pass re-reading dY.
+  const bool do_bias = a.bias_partial != nullptr && c0 == 0 && (wave & 3) == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const s16x8_t ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_raw);
   auto mm = [&](const Frags& f, int half) {
 #pragma unroll
     for (int mi = half * 2; mi < half * 2 + 2; ++mi)
@@ -185,6 +194,11 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
 #pragma unroll
         for (int cf = 0; cf < NCF; ++cf)
           acc[t][mi][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[mi], f.b[t][cf], acc[t][mi][cf], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int mi = half * 2; mi < half * 2 + 2; ++mi)
+        accb[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[mi], ones, accb[mi], 0, 0, 0);
+    }
   };
   auto wait_keep = [&](int tiles_in_flight) {   // leave the DMA of `tiles_in_flight` K-tiles (0..2) outstanding
     if (tiles_in_flight == 0) {
@@ -254,6 +268,25 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
           const int c = c0 + wc0 + cf * 16 + li;
           if (m < a.M && c < a.C) out[((long)t * a.M + m) * a.C + c] = acc[t][mi][cf][r];
         }
+  if (do_bias && li == 0) {      // every column j of D holds the same sum; lane li = 0 writes it
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm0 + mi * 16 + kq * 4 + r;
+        if (m < a.Mp) a.bias_partial[(long)split * a.Mp + m] = accb[mi][r];
+      }
+  }
+}
+
+// dbias[m] (+)= sum_s bias_partial[s][m], fixed order
+static __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* bp, float* dbias, int splits, int Mp, int M,
+                                                                       int accumulate) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += bp[(long)k * Mp + m];
+  dbias[m] = accumulate ? dbias[m] + s : s;
 }
 
 template <int KW, int NCF>
@@ -282,7 +315,8 @@ int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int K
 }
 
 int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
-                                int total_rows, int C, int M, int KW, int w_layout, int accumulate, hipStream_t s) {
+                                int total_rows, int C, int M, int KW, int w_layout, int accumulate, hipStream_t s,
+                                float* dbias, float* bias_partial) {
   const int ct = KW == 3 ? 128 : 256;
   const int Mp = (M + 63) / 64 * 64, Cp = (C + 63) / 64 * 64;
   WgradV2Args a{};
@@ -291,6 +325,7 @@ int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int
     a.x[i] = (const u16*)x[i < nseg ? i : 0];
   }
   a.partial = (float*)workspace;
+  a.bias_partial = dbias ? bias_partial : nullptr;
   a.Mp = Mp; a.Cp = Cp; a.M = M; a.C = C;
   a.mtiles = (M + 127) / 128; a.ctiles = (C + ct - 1) / ct;
   a.total_rows = total_rows; a.nseg = nseg;
@@ -307,6 +342,9 @@ int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int
   int rc = check_launch("alvq_conv1d_wgrad_bf16(v2)");
   if (rc) return rc;
   wgrad_reduce_launch((const float*)workspace, dw, a.splits, KW, M, C, w_layout, accumulate, s);
+  if (dbias)
+    hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bias_partial, dbias,
+                       a.splits, Mp, M, accumulate);
   return check_launch("alvq_conv1d_wgrad_bf16(v2)/reduce");
 }
 
