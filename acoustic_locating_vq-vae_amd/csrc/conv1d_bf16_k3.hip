@@ -37,8 +37,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_k3_kernel(ConvBArgs a) {
   const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
 
   const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);      // same tile order as the v2 kernel
-  const int m0 = (a.relu & 2 ? tile / a.rtiles : tile % a.mtiles) * V2_M;
-  const int r0 = (a.relu & 2 ? tile % a.rtiles : tile / a.mtiles) * V2_R;
+  const int m0 = (tile % a.mtiles) * V2_M;
+  const int r0 = (tile / a.mtiles) * V2_R;
   const int Cp = a.Cp;
 
   // ---- DMA source addressing: a piece is 16 rows x 64 B; lane i -> row i>>2, slot i&3 <- channel group

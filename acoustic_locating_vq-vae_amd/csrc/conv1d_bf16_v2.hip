@@ -17,8 +17,6 @@
 // SIMD alternate on the matrix pipe while the other's loads issue.  LDS rows are 64 B; the 16-B chunk of row r
 // holding channel group g sits in slot g ^ h[(r>>2)&3], h = {0,3,2,1} (applied on the DMA source address and on
 // the read address), which makes every ds_read_b128 fragment read bank-conflict-free.
-#include <stdlib.h>
-
 #include "alvq_common.h"
 #include "bf16_common.h"
 #include "conv1d_bf16_tile256.h"
@@ -30,9 +28,7 @@ constexpr int V2_NSTAGE = 4;
 constexpr int V2_LDS = V2_NSTAGE * V2_STAGE;      // 131072 B
 static_assert(V2_EPI_LDS <= V2_LDS, "C slab must fit");
 
-// DBG (timing experiments; 1-3 give wrong results): 1 = no DMA in the loop, 2 = no vmcnt waits, 3 = no barriers,
-// 4 = no issue stagger (correct results)
-template <int OUT, int DBG = 0>
+template <int OUT>
 __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int KW) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int PAD = (KW - 1) / 2;
@@ -45,8 +41,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
   // workgroups resident on an XCD at one time share both operands through its L2 (W: one miss per m-tile per
   // wave of workgroups; activation rows: one miss per row tile instead of one per m-tile)
   const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int m0 = (a.relu & 2 ? tile / a.rtiles : tile % a.mtiles) * V2_M;
-  const int r0 = (a.relu & 2 ? tile % a.rtiles : tile / a.mtiles) * V2_R;
+  const int m0 = (tile % a.mtiles) * V2_M;
+  const int r0 = (tile / a.mtiles) * V2_R;
   const int Cp = a.Cp;
 
   // ---- DMA source addressing: piece p (16 rows x 64 B); lane i -> row 16p + (i>>2), slot i&3, which must hold
@@ -103,7 +99,6 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
   };
 
   const int n = (Cp / V2_K) * KW;   // K-tiles; always even (Cp % 64 == 0)
-  constexpr bool STAGGER = (DBG != 4);
   const bool early = wave < 4;
   FragSet f0, f1;
 
@@ -129,41 +124,33 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
     // ---- even K-tile t (fragments in f0)
     // stagger: the older four waves issue their DMA before the MFMAs, the younger four (their SIMD partners)
     // between the MFMA halves, so the two waves of a SIMD are not both stuck in DMA issue at the same time
-    if (t + 3 < n && DBG != 1 && (early || !STAGGER)) issue((t + 3) & 3);
+    if (t + 3 < n && early) issue((t + 3) & 3);
     mm(f0, 0);
     __builtin_amdgcn_sched_barrier(0);   // pin: reads go BETWEEN the MFMA halves (hipcc otherwise hoists them
     rd(f1, (t + 1) & 3);                 // above all 32 MFMAs and then waits lgkmcnt(0) in front of the first one)
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 3 < n && DBG != 1 && STAGGER && !early) issue((t + 3) & 3);
+    if (t + 3 < n && !early) issue((t + 3) & 3);
     mm(f0, 1);
-    if (DBG != 2 && DBG != 1) {
-      if (t + 3 < n) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+    if (t + 3 < n) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (DBG != 3) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     // ---- odd K-tile t+1 (fragments in f1)
-    if (t + 4 < n && DBG != 1 && (early || !STAGGER)) issue((t + 4) & 3);
+    if (t + 4 < n && early) issue((t + 4) & 3);
     mm(f1, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (t + 2 < n) rd(f0, (t + 2) & 3);
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 4 < n && DBG != 1 && STAGGER && !early) issue((t + 4) & 3);
+    if (t + 4 < n && !early) issue((t + 4) & 3);
     mm(f1, 1);
-    if (DBG != 2 && DBG != 1) {
-      if (t + 4 < n) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+    if (t + 4 < n) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (DBG != 3) __builtin_amdgcn_s_barrier();
-  }
-  if (DBG != 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
   }
 
   tile256_epilogue<OUT>(a, acc, lds, m0, r0, wave, tid, li, kq, wm0);
@@ -181,17 +168,6 @@ int conv1d_bf16_v2_launch(const ConvBArgs& a_in, int KW, hipStream_t stream) {
     attr = true;
   }
   const dim3 grid(a.rtiles * a.mtiles), block(512);
-  static int dbg = -1;
-  if (dbg < 0) dbg = getenv("ALVQ_DBG") ? atoi(getenv("ALVQ_DBG")) : 0;
-  if (dbg && a.y) {
-    const void* fn = dbg == 1 ? (const void*)conv1d_bf16_v2_kernel<0, 1> : dbg == 2 ? (const void*)conv1d_bf16_v2_kernel<0, 2> : dbg == 3 ? (const void*)conv1d_bf16_v2_kernel<0, 3> : (const void*)conv1d_bf16_v2_kernel<0, 4>;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
-    if (dbg == 1) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 1>), grid, block, V2_LDS, stream, a, KW);
-    else if (dbg == 2) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 2>), grid, block, V2_LDS, stream, a, KW);
-    else if (dbg == 3) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 3>), grid, block, V2_LDS, stream, a, KW);
-    else hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 4>), grid, block, V2_LDS, stream, a, KW);
-    return check_launch("alvq_conv1d_bf16(v2 dbg)");
-  }
   if (a.y) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0>), grid, block, V2_LDS, stream, a, KW);
   else hipLaunchKernelGGL((conv1d_bf16_v2_kernel<1>), grid, block, V2_LDS, stream, a, KW);
   return check_launch("alvq_conv1d_bf16(v2)");

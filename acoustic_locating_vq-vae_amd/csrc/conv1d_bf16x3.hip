@@ -385,23 +385,6 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
         }
 }
 
-// ------------------------------------------------------------------------------------------- helpers (split forms)
-__global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float* w, u16* wp, long plane, int M, int C, int KW, int Mp,
-                                                             int Cp, int w_layout) {
-  const long total = (long)KW * Mp * Cp;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c = (int)(e % Cp);
-    const int m = (int)((e / Cp) % Mp);
-    const int t = (int)(e / ((long)Cp * Mp));
-    float v = 0.f;
-    if (m < M && c < C) v = w_layout == ALVQ_W_OIK ? w[((long)m * C + c) * KW + t] : w[((long)c * M + m) * KW + (KW - 1 - t)];
-    u16 hi, lo;
-    split2(v, hi, lo);
-    wp[e] = hi;
-    wp[plane + e] = lo;
-  }
-}
-
 __global__ __launch_bounds__(256) void ncl_to_nlc_x3_kernel(const float* x, u16* y, long plane, int B, int C, int L, int Cp,
                                                             int rows_total) {
   __shared__ float tile[32][33];
@@ -544,15 +527,8 @@ extern "C" int64_t alvq_nlc_plane_bytes(int B, int L, int C) {
 }
 
 extern "C" int alvq_pack_weight_bf16x3(const float* w, void* wp, int M, int C, int KW, int w_layout, void* stream) {
-  ALVQ_REQUIRE(w && wp, ALVQ_EINVAL, "alvq_pack_weight_bf16x3: null pointer");
-  ALVQ_REQUIRE(M > 0 && C > 0 && (KW == 1 || KW == 3), ALVQ_EINVAL, "alvq_pack_weight_bf16x3: bad dims");
-  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_pack_weight_bf16x3: w_layout");
-  const long total = alvq_packed_weight_elems(M, C, KW);
-  int grid = (int)((total + 1023) / 1024);
-  if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(pack_weight_x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (u16*)wp, total, M, C, KW,
-                     pad_to(M, WP_ROWS), pad_to(C, 64), w_layout);
-  return check_launch("alvq_pack_weight_bf16x3");
+  const alvq_pack_desc d{w, wp, M, C, KW, w_layout};     // one-descriptor batch, hi + lo images (pack_weights.hip)
+  return alvq_pack_weights_bf16_batch(&d, 1, 2, stream);
 }
 
 extern "C" int alvq_ncl_to_nlc_bf16x3(const float* x, void* y, int B, int C, int L, void* stream) {
