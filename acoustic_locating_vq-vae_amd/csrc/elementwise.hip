@@ -155,6 +155,18 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g,
   }
 }
 
+// Advance the device-side step counter and derive that step's scalars from it (double arithmetic, as the host
+// would): sc = {lr/(1-beta1^t), sqrt(1-beta2^t), grad_scale, t}.  No host buffer is involved, so nothing races when
+// the host queues many steps ahead of the device, and the launch can be replayed from a graph.
+__global__ void adam_advance_kernel(float* sc, double lr, double beta1, double beta2, double grad_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double t = (double)sc[3] + 1.0;
+  sc[0] = (float)(lr / (1.0 - pow(beta1, t)));
+  sc[1] = (float)sqrt(1.0 - pow(beta2, t));
+  sc[2] = (float)grad_scale;
+  sc[3] = (float)t;
+}
+
 }  // namespace alvq
 
 using namespace alvq;
@@ -241,4 +253,10 @@ extern "C" int alvq_adam_dev_f32(float* param, const float* grad, float* exp_avg
   hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
                      (long)n, scalars, beta1, beta2, eps);
   return check_launch("alvq_adam_dev_f32");
+}
+
+extern "C" int alvq_adam_advance_f32(float* scalars, double lr, double beta1, double beta2, double grad_scale, void* stream) {
+  ALVQ_REQUIRE(scalars, ALVQ_EINVAL, "alvq_adam_advance_f32: null pointer");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scalars, lr, beta1, beta2, grad_scale);
+  return check_launch("alvq_adam_advance_f32");
 }

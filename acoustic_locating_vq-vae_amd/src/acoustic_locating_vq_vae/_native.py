@@ -48,6 +48,7 @@ _SIGNATURES = {
     "alvq_transpose_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_adam_f32": (_i32, [_c_void_p] * 4 + [_i64, _i32, _f32, _f32, _f32, _f32, _f32, _c_void_p]),
     "alvq_adam_dev_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p, _f32, _f32, _f32, _c_void_p]),
+    "alvq_adam_advance_f32": (_i32, [_c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_void_p]),
     "alvq_stft_power_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_stft_power_f64": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_nlc_rows": (_i64, [_i32, _i32]),
@@ -350,10 +351,19 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, beta1=0.9, beta2=
 
 
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.999, eps=1e-8):
-    """Adam with {lr/bc1, sqrt(bc2), grad_scale} read from the 3-float device tensor ``scalars`` (graph-replayable)."""
+    """Adam with {lr/bc1, sqrt(bc2), grad_scale} read from the first 3 floats of the device tensor ``scalars``
+    (graph-replayable; ``adam_advance`` maintains them)."""
     _check(lib().alvq_adam_dev_f32(_ptr(param, name="param"), _ptr(grad, name="grad"), _ptr(exp_avg, name="exp_avg"),
                                    _ptr(exp_avg_sq, name="exp_avg_sq"), param.numel(), _ptr(scalars, name="scalars"),
                                    float(beta1), float(beta2), float(eps), _stream()), "alvq_adam_dev_f32")
+
+
+def adam_advance(scalars, lr, beta1=0.9, beta2=0.999, grad_scale=1.0):
+    """Device-side ``step += 1`` on the 4-float tensor ``scalars`` = {lr/bc1, sqrt(bc2), grad_scale, step}."""
+    if scalars.numel() != 4:
+        raise RuntimeError("adam_advance: scalars must hold 4 floats")
+    _check(lib().alvq_adam_advance_f32(_ptr(scalars, name="scalars"), float(lr), float(beta1), float(beta2),
+                                       float(grad_scale), _stream()), "alvq_adam_advance_f32")
 
 
 def stft_power(wave, n_fft=400, hop=160):

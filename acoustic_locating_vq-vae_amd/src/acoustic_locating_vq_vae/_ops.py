@@ -100,17 +100,40 @@ class PackPool:
 
 _ACTIVE_POOL = None
 
+# two-part backward (train_step.Trainer): while a list is installed here, ConvolutionalVQVAE.forward hands the
+# encoder output over as a detached leaf and records (graph output, leaf) so the trainer can run
+# ``loss.backward()`` (fills leaf.grad) and later ``output.backward(leaf.grad)``.
+_LATENT_TAP = None
+
+
+def tap_latent(z):
+    leaf = z.detach().requires_grad_(True)
+    _LATENT_TAP.append((z, leaf))
+    return leaf
+
+
+class latent_tap:
+    def __enter__(self):
+        global _LATENT_TAP
+        self.prev, _LATENT_TAP = _LATENT_TAP, []
+        return _LATENT_TAP
+
+    def __exit__(self, *exc):
+        global _LATENT_TAP
+        _LATENT_TAP = self.prev
+
+
 
 class use_pack_pool:
     """with use_pack_pool(pool): ...  -- the body of a trainer step"""
 
-    def __init__(self, pool):
-        self.pool = pool
+    def __init__(self, pool, refresh=True):
+        self.pool, self.do_refresh = pool, refresh
 
     def __enter__(self):
         global _ACTIVE_POOL
         self.prev, _ACTIVE_POOL = _ACTIVE_POOL, self.pool
-        if self.pool is not None:
+        if self.pool is not None and self.do_refresh:
             self.pool.refresh()
 
     def __exit__(self, *exc):

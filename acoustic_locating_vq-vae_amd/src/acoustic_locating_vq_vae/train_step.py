@@ -5,9 +5,12 @@ train_rir.py:42-58,72-75; train_echoed_speech.py:62-75,89-92) and has no multi-G
 reproduces one step of each loop on the HIP path and adds what the north star asks for:
 
 * ``FlatBuffers``   -- every trainable parameter (and its ``.grad``) is a view into one flat fp32 buffer;
-* ``sync_grads``    -- exactly ONE all-reduce(sum) of the flat gradient buffer per step (RCCL over xGMI when the
-                       process group backend is "nccl"; "gloo" on CPU for tests), the 1/world factor is folded
-                       into the optimiser kernel;
+* ``sync_grads`` / ``sync_span`` -- the step's all-reduce(sum) of the flat gradient buffer (RCCL over xGMI when
+                       the process group backend is "nccl"; "gloo" on CPU for tests); the 1/world factor is folded
+                       into the optimiser kernel.  The buffer is reduced exactly once per step.  By default the
+                       VQ-VAE trainers issue that reduction as two contiguous spans -- quantiser + decoder gradients
+                       as soon as they exist, encoder gradients at the end -- so the first overlaps the encoder's
+                       backward (``ALVQ_GRAD_BUCKETS=1`` / ``Trainer(grad_buckets=1)``: one call after the backward);
 * ``FlatAdam``      -- torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, amsgrad=False) arithmetic
                        (train_speech.py:154) as one HIP launch over the flat buffer.
 
@@ -67,7 +70,7 @@ class FlatBuffers:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)
 
     def sync_grads(self, group=None):
-        """The step's single collective: all-reduce(sum) of the flat gradient buffer, in place.
+        """All-reduce(sum) of the whole flat gradient buffer, in place, as ONE collective.
         Returns the factor the optimiser must apply (1/world)."""
         if not (dist.is_available() and dist.is_initialized()):
             return 1.0
@@ -77,36 +80,52 @@ class FlatBuffers:
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / world
 
+    def span(self, params):
+        """[lo, hi) of the flat buffers covering ``params`` -- which must be a contiguous run of ``self.params``."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)) or len(idx) != len(ids):
+            raise ValueError("bucket parameters are not a contiguous run of the flat buffer")
+        last = idx[-1]
+        hi = self.offsets[last + 1] if last + 1 < len(self.offsets) else self.grad.numel()
+        return self.offsets[idx[0]], hi
+
+    def sync_span(self, lo, hi, group=None):
+        """Asynchronous all-reduce(sum) of grad[lo:hi); returns the work handle (None without a process group).  The
+        caller ``wait()``s it -- a stream-level wait on the GPU -- before the optimiser reads the buffer."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
+
     def broadcast_params(self, src=0, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.flat, src=src, group=group)
 
 
 class FlatAdam:
-    """Adam over FlatBuffers as one HIP kernel launch.
+    """Adam over FlatBuffers as HIP launches over the flat buffer.
 
-    The step-dependent scalars (lr/bias_correction1, sqrt(bias_correction2), grad_scale) live in a 3-float
-    device buffer that ``prepare()`` refreshes from pinned host memory, so ``apply()`` -- the launch itself --
-    can sit inside a captured hipGraph and be replayed every step."""
+    The step-dependent scalars (lr/bias_correction1, sqrt(bias_correction2), grad_scale) and the step counter live
+    in a 4-float DEVICE buffer; ``prepare()`` advances them with a one-thread kernel in stream order.  Nothing is
+    staged through host memory, so a host that queues many steps ahead of the device (graph replay does) cannot
+    overwrite a step's scalars before that step's Adam launch has read them."""
 
     def __init__(self, buffers: FlatBuffers, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.b = buffers
         self.lr, self.betas, self.eps = lr, betas, eps
         self.exp_avg = torch.zeros_like(buffers.flat)
         self.exp_avg_sq = torch.zeros_like(buffers.flat)
-        self.step_count = 0
-        self.scalars = torch.zeros(3, device=buffers.flat.device, dtype=torch.float32)
-        self._host = torch.zeros(3, dtype=torch.float32)
-        if buffers.flat.is_cuda:
-            self._host = self._host.pin_memory()
+        self.step_count = 0                                   # host mirror of scalars[3]
+        self.scalars = torch.zeros(4, device=buffers.flat.device, dtype=torch.float32)
+
+    def set_step(self, step):
+        """Resume from a checkpointed step count."""
+        self.step_count = int(step)
+        self.scalars[3] = float(step)
 
     def prepare(self, grad_scale=1.0):
         self.step_count += 1
-        b1, b2 = self.betas
-        self._host[0] = self.lr / (1.0 - b1 ** self.step_count)
-        self._host[1] = (1.0 - b2 ** self.step_count) ** 0.5
-        self._host[2] = grad_scale
-        self.scalars.copy_(self._host, non_blocking=True)
+        N.adam_advance(self.scalars, self.lr, self.betas[0], self.betas[1], grad_scale)
 
     def apply(self):
         N.adam_step_dev(self.b.flat, self.b.grad, self.exp_avg, self.exp_avg_sq, self.scalars, self.betas[0],
@@ -134,7 +153,7 @@ class Trainer:
     kind="echoed":  x = standardise(echoed); x_rir = x^T; loss = mse(recon, x)                (train_echoed_speech.py)
     """
 
-    def __init__(self, model, kind="speech", lr=1e-3, group=None):
+    def __init__(self, model, kind="speech", lr=1e-3, group=None, grad_buckets=None):
         self.model, self.kind, self.group = model, kind, group
         params = model._decoder.parameters() if kind == "echoed" else model.parameters()
         if kind == "echoed":
@@ -153,6 +172,20 @@ class Trainer:
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.grad_scale = 1.0 / world
         self._graph = None
+        # Two gradient buckets for the VQ-VAE loops: "late" = encoder + pre-VQ conv (a prefix of the flat buffer, its
+        # gradients are produced last), "early" = quantiser + decoder.  The backward runs in two parts so the early
+        # bucket's all-reduce overlaps the late part's kernels (see ``step``).  The echoed loop trains the decoder
+        # only: one part, one bucket.
+        self._buckets = None
+        want_buckets = int(os.environ.get("ALVQ_GRAD_BUCKETS", "2")) if grad_buckets is None else grad_buckets
+        if want_buckets >= 2 and kind != "echoed" and hasattr(model, "_encoder") and hasattr(model, "_pre_vq_conv"):
+            late = unique_trainable(list(model._encoder.parameters()) + list(model._pre_vq_conv.parameters()))
+            late_ids = {id(p) for p in late}
+            early = [p for p in self.buffers.params if id(p) not in late_ids]
+            if late and early:
+                self._late_params, self._early_params = late, early
+                self._buckets = (self.buffers.span(early), self.buffers.span(late))
+        self._cut = None
 
     def preprocess(self, raw, wiener=None):
         if self.kind == "speech":
@@ -176,19 +209,44 @@ class Trainer:
         return recon_error + vq_loss, recon_error, perplexity
 
     def _body(self, raw, wiener):
-        """Preprocess + forward + backward: the launch-bound part of a step (~150 launches) that a hipGraph
-        captures.  The collective and the optimiser launch stay outside (``_finish``) so no RCCL call is ever
-        recorded into a graph."""
+        """Preprocess + forward + first part of the backward (everything above the encoder output, or the whole
+        backward when the model has a single bucket).  ``_body`` and ``_body_late`` are the launch-bound part of a
+        step (~130 launches) that hipGraphs capture; the collectives and the optimiser launch stay outside so no
+        RCCL call is ever recorded into a graph."""
         with _ops.use_pack_pool(self.pack_pool):            # one batched re-pack of every conv weight, then lookups
             x, target = self.preprocess(raw, wiener)
             self.buffers.zero_grad()
-            loss, recon_error, perplexity = self.forward_loss(x, target)
-            loss.backward()
+            if self._buckets is None:
+                loss, recon_error, perplexity = self.forward_loss(x, target)
+                loss.backward()
+            else:
+                with _ops.latent_tap() as tap:
+                    loss, recon_error, perplexity = self.forward_loss(x, target)
+                loss.backward()                              # decoder, quantiser -> early bucket + d(latent)
+                self._cut = tap[0] if tap else None
         return loss.detach(), recon_error.detach(), perplexity.detach()
 
-    def _finish(self):
-        self.buffers.sync_grads(self.group)            # the step's single collective (eager, on the same stream)
-        self.opt.apply()                               # one Adam launch over the flat buffer
+    def _body_late(self):
+        """Second part of the backward: the encoder and the pre-VQ conv, from the latent's gradient."""
+        if self._cut is None:
+            return
+        z, leaf = self._cut
+        self._cut = None
+        with _ops.use_pack_pool(self.pack_pool, refresh=False):
+            z.backward(leaf.grad)
+
+    def _sync_early(self):
+        return self.buffers.sync_span(*self._buckets[0], group=self.group) if self._buckets else None
+
+    def _finish(self, early_work=None):
+        if self._buckets is None:
+            self.buffers.sync_grads(self.group)                # single bucket: the step's one collective
+        else:
+            late_work = self.buffers.sync_span(*self._buckets[1], group=self.group)
+            for w in (early_work, late_work):
+                if w is not None:
+                    w.wait()                                   # stream-level wait: the Adam launch queues behind both
+        self.opt.apply()                                       # one Adam launch over the flat buffer
 
     def _jitters(self):
         from .vq_vae.modules.jitter import Jitter
@@ -197,13 +255,18 @@ class Trainer:
         return [m for m in self.model.modules() if isinstance(m, Jitter)]
 
     def step(self, raw, wiener=None):
-        """Returns (loss, recon_error, perplexity) as 0-dim device tensors -- no host sync in here."""
+        """Returns (loss, recon_error, perplexity) as 0-dim device tensors -- no host sync in here.
+
+        Order on the stream:  part 1 (fwd + decoder/quantiser backward)  ->  all-reduce(early bucket) starts  ->
+        part 2 (encoder backward) runs while it is in flight  ->  all-reduce(late bucket)  ->  Adam."""
         if self._graph is None:
             self.opt.prepare(self.grad_scale)
             out = self._body(raw, wiener)
-            self._finish()
+            early = self._sync_early()
+            self._body_late()
+            self._finish(early)
             return out
-        # replay: refresh the graph's static inputs (batch, jitter columns, Adam scalars), then one launch
+        # replay: refresh the graphs' static inputs (batch, jitter columns, Adam scalars), then two launches
         self._static_raw.copy_(raw, non_blocking=True)
         if wiener is not None:
             self._static_wiener.copy_(wiener, non_blocking=True)
@@ -211,12 +274,15 @@ class Trainer:
             j.refresh()
         self.opt.prepare(self.grad_scale)
         self._graph.replay()
-        self._finish()
+        early = self._sync_early()
+        if self._graph_late is not None:
+            self._graph_late.replay()
+        self._finish(early)
         return self._static_out
 
     def capture(self, raw, wiener=None, warmup=3):
-        """Capture preprocess + forward + backward into one hipGraph (launch-bound inner loop: ~150 launches per
-        step).  Runs ``warmup`` real training steps first (allocator + workspaces reach steady state)."""
+        """Capture the two launch-bound parts of a step into hipGraphs (one memory pool).  Runs ``warmup`` real
+        training steps first (allocator + workspaces + packed-weight pool reach steady state)."""
         assert self._graph is None, "already captured"
         self._static_raw = raw.clone()
         self._static_wiener = wiener.clone() if wiener is not None else None
@@ -232,11 +298,18 @@ class Trainer:
                     j.refresh()
                 self.opt.prepare(self.grad_scale)
                 self._body(self._static_raw, self._static_wiener)
-                self._finish()
+                early = self._sync_early()
+                self._body_late()
+                self._finish(early)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._static_out = self._body(self._static_raw, self._static_wiener)
-        self._graph = graph
+        graph_late = None
+        if self._cut is not None:
+            graph_late = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_late, pool=graph.pool()):
+                self._body_late()
+        self._graph, self._graph_late = graph, graph_late
         return self

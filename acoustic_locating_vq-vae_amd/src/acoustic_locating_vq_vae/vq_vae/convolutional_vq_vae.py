@@ -47,6 +47,10 @@ class ConvolutionalVQVAE(nn.Module):
 
     def forward(self, x):
         z = self._latent(x)
+        if _ops._LATENT_TAP is not None and z.requires_grad:
+            # train_step.Trainer runs the backward in two parts (decoder + quantiser, then encoder) so that the
+            # first gradient bucket's all-reduce overlaps the second part: cut the autograd graph here.
+            z = _ops.tap_latent(z)
         if self.encoder_average_pooling:
             z = torch.mean(z, dim=2, keepdim=True)
         loss, quantized, perplexity, _ = self._vq.quantize(z)

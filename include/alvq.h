@@ -150,6 +150,12 @@ int alvq_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_av
 int alvq_adam_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const float* scalars, float beta1, float beta2, float eps, void* stream);
 
+/* Device-side step counter for the form above: scalars is FOUR floats, {.., .., .., step} (step starts at 0).  Each
+ * call does step += 1 and rewrites the first three for that step, in stream order -- no host staging buffer, so a
+ * host that queues steps ahead of the device cannot overwrite a step's scalars before its Adam launch reads them
+ * (hyper-parameters and powers in double, as torch.optim.Adam computes them; exact step count up to 2^24). */
+int alvq_adam_advance_f32(float* scalars, double lr, double beta1, double beta2, double grad_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * STFT power spectrogram (scripts/genereate_dataset.py:90-91,37,39,47-49; torchaudio Spectrogram semantics:
  * center=True reflect pad, periodic Hann(n_fft), one-sided, window-normalised, |.|^2).

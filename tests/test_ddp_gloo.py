@@ -37,7 +37,7 @@ def _loss(p, x, O):
     return F.mse_loss(out["recon"], x) + out["vq_loss"]
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, spans=False):
     _setup_paths()
     from oracle import vqvae_oracle as O
     from acoustic_locating_vq_vae.train_step import FlatBuffers, shard_batch
@@ -65,9 +65,24 @@ def _worker(rank, world, port, ret):
     x = shard_batch(xg, rank, world)
     fb.zero_grad()
     _loss(p, x, O).backward()
-    scale = fb.sync_grads()
-    assert calls["n"] == 1, "exactly one collective per step"
-    assert abs(scale - 1.0 / world) < 1e-12
+    if spans:
+        # the trainers' default: the same reduction issued as two contiguous spans (early = quantiser + decoder,
+        # late = encoder + pre-VQ conv, a prefix of the buffer), each element reduced exactly once
+        names = list(p)
+        cut = next(i for i, k in enumerate(names) if not (k.startswith("_encoder") or k.startswith("_pre_vq")))
+        late, early = [p[k] for k in names[:cut]], [p[k] for k in names[cut:]]
+        (elo, ehi), (llo, lhi) = fb.span(early), fb.span(late)
+        assert llo == 0 and lhi == elo and ehi == fb.grad.numel(), "the two spans partition the flat buffer"
+        w_early = fb.sync_span(elo, ehi)
+        w_late = fb.sync_span(llo, lhi)
+        w_early.wait()
+        w_late.wait()
+        assert calls["n"] == 2
+        scale = 1.0 / world
+    else:
+        scale = fb.sync_grads()
+        assert calls["n"] == 1, "exactly one collective per step"
+        assert abs(scale - 1.0 / world) < 1e-12
     grads = (fb.grad * scale).clone()
     with torch.no_grad():
         fb.flat.add_(grads, alpha=-0.1)             # any deterministic optimiser: ranks must stay identical
@@ -81,12 +96,13 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_grads_equal_single_rank_on_full_batch():
+@pytest.mark.parametrize("spans", [False, True])
+def test_two_rank_grads_equal_single_rank_on_full_batch(spans):
     _setup_paths()
     from oracle import vqvae_oracle as O
     from acoustic_locating_vq_vae.train_step import FlatBuffers
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ret, spans), nprocs=2, join=True)
     assert ret["same"] and ret["views_alive"]
     shapes = O.vqvae_param_shapes(7, 16, 4, 8, 16)
     p = {k: v.clone().requires_grad_(True) for k, v in O.closed_form_params(shapes, 0.8).items()}

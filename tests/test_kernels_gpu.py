@@ -195,6 +195,30 @@ def test_adam_matches_torch():
     assert float((p.cpu() - ref.detach()).abs().max()) < 2e-6
 
 
+def test_adam_device_step_counter_matches_torch_without_host_syncs():
+    """adam_advance + adam_step_dev (the trainers' form: step counter and bias corrections on the device) track
+    torch.optim.Adam when all steps are queued back to back with no host synchronisation in between."""
+    torch.manual_seed(11)
+    n = 50001
+    p0 = torch.randn(n)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, amsgrad=False)
+    grads = [torch.randn(n) for _ in range(6)]
+    gdev = [dev(g) for g in grads]
+    p, m, v = dev(p0.clone()), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    scalars = torch.zeros(4, device="cuda")
+    torch.cuda.synchronize()
+    for g in gdev:                                   # no sync inside: every step's scalars come from the device
+        N.adam_advance(scalars, 1e-3, 0.9, 0.999, 1.0)
+        N.adam_step_dev(p, g, m, v, scalars)
+    for g in grads:
+        ref.grad = g.clone()
+        opt.step()
+    assert float(scalars[3]) == 6.0
+    assert abs(float(scalars[0]) - 1e-3 / (1 - 0.9 ** 6)) < 1e-9 and abs(float(scalars[1]) - (1 - 0.999 ** 6) ** 0.5) < 1e-8
+    assert float((p.cpu() - ref.detach()).abs().max()) < 3e-6
+
+
 def test_stft_power_unpinned(golden_dir):
     """PARITY UNPINNED (torchaudio absent): checked against the torch.stft restatement and a fp64 direct DFT."""
     import os
