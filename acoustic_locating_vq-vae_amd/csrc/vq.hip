@@ -241,32 +241,109 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const float* partials,
   }
 }
 
-constexpr int VQ_PRIV = 16;   // private copies of dE the scatter-add is spread over (hot codes serialise on one copy)
-
-// priv: VQ_PRIV x K x D zeroed floats (or NULL: add straight into dE).
-__global__ __launch_bounds__(256) void vq_backward_kernel(const float* g, const float* grad_loss, const float* x,
-                                                          const float* e, const int64_t* idx, float* dx, float* dE,
-                                                          float* priv, long N, int K, int D, float cx, float ce) {
+// dx = g - gl*cx*(E[idx] - x)  (one wave per row)
+__global__ __launch_bounds__(256) void vq_backward_dx_kernel(const float* g, const float* grad_loss, const float* x,
+                                                             const float* e, const int64_t* idx, float* dx, long N, int D,
+                                                             float cx) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float gl = grad_loss ? grad_loss[0] : 1.f;
-  const float sx = gl * cx, se = gl * ce;
-  float* acc = dE ? (priv ? priv + (long)(blockIdx.x % VQ_PRIV) * K * D : dE) : nullptr;
+  const float sx = (grad_loss ? grad_loss[0] : 1.f) * cx;
   for (long r = (long)blockIdx.x * 4 + wave; r < N; r += (long)gridDim.x * 4) {
     const long k = idx[r];
     for (int d = lane; d < D; d += 64) {
-      const float xv = x[r * D + d];
-      const float diff = e[k * D + d] - xv;  // q - x
-      if (dx) dx[r * D + d] = (g ? g[r * D + d] : 0.f) - sx * diff;
-      if (acc) atomicAdd(&acc[k * D + d], se * diff);
+      const float diff = e[k * D + d] - x[r * D + d];  // q - x
+      dx[r * D + d] = (g ? g[r * D + d] : 0.f) - sx * diff;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void vq_priv_reduce_kernel(const float* priv, float* dE, long kd) {
+// dE[k] += gl*ce * sum_{n: idx_n = k} (E[k] - x_n), WITHOUT atomics.  Workgroup (k, p) owns code k on the p-th of P
+// contiguous row segments: it scans the segment's idx in row order, compacts the matching row numbers into an LDS
+// list (block prefix sum, order preserved) and sums those rows in a fixed pattern -- G thread groups take list
+// positions g, g+G, ... and are combined in group order -- into partial[p][k][:].  A second tiny kernel adds the P
+// partials in segment order.  Every sum's order depends on the data only: bitwise reproducible from run to run
+// (float atomics are not), and a hot code is spread over P workgroups x G groups instead of serialising.
+constexpr int VQL_CAP = 2048;       // list capacity (rows of one code gathered before a flush)
+constexpr int VQL_CHUNK = 1024;     // rows scanned per iteration (4 per thread)
+template <int VEC>                  // VEC = 4: D % 4 == 0, float4 lanes; VEC = 1: any D <= 256
+__global__ __launch_bounds__(256) void vq_codebook_grad_kernel(const float* grad_loss, const float* x, const float* e,
+                                                               const int64_t* idx, float* partial, long N, int K, int D,
+                                                               long rows_per_part, float ce) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ int list[VQL_CAP];
+  __shared__ int wave_tot[4];
+  __shared__ vec_t comb[256];
+  const int k = blockIdx.x, part = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float se = (grad_loss ? grad_loss[0] : 1.f) * ce;
+  const int TD = D / VEC;                          // lanes along d (<= 128 for VEC = 4, <= 256 for VEC = 1)
+  const int G = 256 / TD;                          // thread groups
+  const int grp = tid / TD, ld = tid - grp * TD;
+  const bool summer = grp < G;
+  vec_t ek, acc;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    ek[v] = summer ? e[(long)k * D + ld * VEC + v] : 0.f;
+    acc[v] = 0.f;
+  }
+  int nlist = 0;
+  auto flush = [&]() {
+    if (!summer) return;
+    int i = grp;
+    for (; i + G < nlist; i += 2 * G) {            // two rows in flight per thread
+      const vec_t a = *(const vec_t*)(x + (long)list[i] * D + ld * VEC);
+      const vec_t b = *(const vec_t*)(x + (long)list[i + G] * D + ld * VEC);
+      acc += se * (ek - a);
+      acc += se * (ek - b);
+    }
+    if (i < nlist) acc += se * (ek - *(const vec_t*)(x + (long)list[i] * D + ld * VEC));
+  };
+  const long rbeg = (long)part * rows_per_part;
+  const long rend = rbeg + rows_per_part < N ? rbeg + rows_per_part : N;
+  for (long base = rbeg; base < rend; base += VQL_CHUNK) {
+    int mine[4], cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long r = base + 4 * tid + j;
+      if (r < rend && idx[r] == k) mine[cnt++] = (int)r;
+    }
+    int incl = cnt;                                // inclusive prefix over the wave, then over the block
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) before += wave_tot[w];
+      total += wave_tot[w];
+    }
+    const int pos = nlist + before + incl - cnt;
+    for (int j = 0; j < cnt; ++j) list[pos + j] = mine[j];
+    nlist += total;
+    __syncthreads();
+    if (nlist > VQL_CAP - VQL_CHUNK) {             // the next chunk might not fit: sum what is gathered
+      flush();
+      nlist = 0;
+      __syncthreads();
+    }
+  }
+  flush();
+  comb[tid] = acc;
+  __syncthreads();
+  if (tid < TD) {
+    vec_t s = comb[tid];
+    for (int g = 1; g < G; ++g) s += comb[g * TD + tid];
+    *(vec_t*)(partial + ((long)part * K + k) * D + tid * VEC) = s;
+  }
+}
+
+// dE (+)= sum_p partial[p], segment order
+__global__ __launch_bounds__(256) void vq_codebook_grad_reduce_kernel(const float* partial, float* dE, long kd, int P) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < kd; i += (long)gridDim.x * 256) {
     float s = 0.f;
-#pragma unroll
-    for (int p = 0; p < VQ_PRIV; ++p) s += priv[p * kd + i];
+    for (int p = 0; p < P; ++p) s += partial[(long)p * kd + i];
     dE[i] += s;
   }
 }
@@ -344,8 +421,15 @@ extern "C" int alvq_vq_finalize_f32(const float* sq_partials, const int32_t* his
   return check_launch("alvq_vq_finalize_f32");
 }
 
+constexpr int VQ_PARTS_MAX = 16;   // row segments a code's gather is split over
+
+static int vq_parts(int64_t N) {
+  int64_t p = N / 4096;
+  return p < 1 ? 1 : (p > VQ_PARTS_MAX ? VQ_PARTS_MAX : (int)p);
+}
+
 extern "C" int64_t alvq_vq_backward_workspace_bytes(int K, int D) {
-  return (K <= 0 || D <= 0) ? -1 : (int64_t)VQ_PRIV * K * D * (int64_t)sizeof(float);
+  return (K <= 0 || D <= 0) ? -1 : (int64_t)VQ_PARTS_MAX * K * D * (int64_t)sizeof(float);
 }
 
 extern "C" int alvq_vq_backward_f32(const float* g, const float* grad_loss, const float* x, const float* codebook,
@@ -353,18 +437,27 @@ extern "C" int alvq_vq_backward_f32(const float* g, const float* grad_loss, cons
                                     float beta, void* stream) {
   ALVQ_REQUIRE(x && codebook && idx && (dx || dE), ALVQ_EINVAL, "alvq_vq_backward_f32: null pointer");
   ALVQ_REQUIRE(N > 0 && K > 0 && D > 0, ALVQ_EINVAL, "alvq_vq_backward_f32: bad dims");
+  ALVQ_REQUIRE(!dE || workspace, ALVQ_EINVAL, "alvq_vq_backward_f32: the codebook gradient needs the workspace");
+  ALVQ_REQUIRE(N < (1L << 31) && K <= 65535 && ((D % 4 == 0 && D <= 512) || D <= 256), ALVQ_EUNSUPPORTED,
+               "alvq_vq_backward_f32: N=%ld K=%d D=%d outside the supported range", (long)N, K, D);
   const double nd = (double)N * (double)D;
   hipStream_t s = (hipStream_t)stream;
-  float* priv = dE ? (float*)workspace : nullptr;
-  if (priv) {
-    hipError_t e = hipMemsetAsync(priv, 0, (size_t)VQ_PRIV * K * D * sizeof(float), s);
-    ALVQ_REQUIRE(e == hipSuccess, (int)e, "alvq_vq_backward_f32: memset: %s", hipGetErrorString(e));
+  if (dx)
+    hipLaunchKernelGGL(vq_backward_dx_kernel, dim3(grid_for(N, 4)), dim3(256), 0, s, g, grad_loss, x, codebook, idx, dx,
+                       (long)N, D, (float)(2.0 * beta / nd));
+  if (dE) {
+    const int P = vq_parts(N);
+    const long rpp = ((N + P - 1) / P + VQL_CHUNK - 1) / VQL_CHUNK * VQL_CHUNK;
+    float* partial = (float*)workspace;
+    if (D % 4 == 0)
+      hipLaunchKernelGGL(vq_codebook_grad_kernel<4>, dim3(K, P), dim3(256), 0, s, grad_loss, x, codebook, idx, partial, (long)N,
+                         K, D, rpp, (float)(2.0 / nd));
+    else
+      hipLaunchKernelGGL(vq_codebook_grad_kernel<1>, dim3(K, P), dim3(256), 0, s, grad_loss, x, codebook, idx, partial, (long)N,
+                         K, D, rpp, (float)(2.0 / nd));
+    hipLaunchKernelGGL(vq_codebook_grad_reduce_kernel, dim3(grid_for((long)K * D, 256)), dim3(256), 0, s,
+                       (const float*)partial, dE, (long)K * D, P);
   }
-  hipLaunchKernelGGL(vq_backward_kernel, dim3(grid_for(N, 4)), dim3(256), 0, s, g, grad_loss, x, codebook, idx, dx, dE,
-                     priv, (long)N, K, D, (float)(2.0 * beta / nd), (float)(2.0 / nd));
-  if (priv)
-    hipLaunchKernelGGL(vq_priv_reduce_kernel, dim3(grid_for((long)K * D, 256)), dim3(256), 0, s, (const float*)priv, dE,
-                       (long)K * D);
   return check_launch("alvq_vq_backward_f32");
 }
 

@@ -98,10 +98,11 @@ int alvq_vq_finalize_f32(const float* sq_partials, const int32_t* hist, float* o
 
 /* Backward:  dx = g + gl*(2*beta/(N*D))*(x - E[idx]);
  * dE[k] += gl*(2/(N*D)) * sum_{n: idx_n = k} (E[k] - x_n)  (skipped when dE == NULL, i.e. _train_vq False);
- * g = grad wrt q_st (may be NULL = 0), gl = *grad_loss (device scalar, may be NULL = 1).  dE must be zeroed by the
- * caller.  The scatter-add uses float atomics (the only ones on the path); with `workspace`
- * (alvq_vq_backward_workspace_bytes(K,D) bytes, may be NULL) it is spread over private copies so hot codes do
- * not serialise. */
+ * g = grad wrt q_st (may be NULL = 0), gl = *grad_loss (device scalar, may be NULL = 1).  dE is accumulated into
+ * (zero it first for a plain gradient).  No atomics: workgroups (code, row segment) gather their rows in row order
+ * and sum them in a fixed pattern, partials are added in segment order, so the result is bitwise reproducible.
+ * `workspace`: alvq_vq_backward_workspace_bytes(K,D) bytes, required when dE != NULL.  D % 4 == 0 and D <= 512,
+ * or D <= 256. */
 int64_t alvq_vq_backward_workspace_bytes(int K, int D);
 int alvq_vq_backward_f32(const float* g, const float* grad_loss, const float* x, const float* codebook,
                          const int64_t* idx, float* dx, float* dE, void* workspace, int64_t N, int K, int D, float beta,

@@ -233,3 +233,33 @@ def test_stft_power_unpinned(golden_dir):
     w64 = torch.from_numpy(g["wave"]).view(1, -1)                     # float64, as the echoed signal is
     got64 = N.stft_power(dev(w64))
     assert got64.dtype == torch.float64 and rel(got64, torch.from_numpy(g["power_f64"])) < 1e-10
+
+
+@pytest.mark.parametrize("n,K,D,hot", [(5000, 64, 128, True), (33000, 1024, 128, False), (70000, 16, 8, True), (4100, 8, 320, True), (3000, 7, 6, True)])
+def test_vq_codebook_gradient_is_atomic_free_and_reproducible(n, K, D, hot):
+    """dE from the one-workgroup-per-code gather (no atomics): equal to the index_add formulation, bitwise identical
+    from run to run, including a code that owns more rows than the kernel's gather list holds (several flushes)."""
+    torch.manual_seed(12)
+    x = torch.randn(n, D)
+    E = torch.randn(K, D) * 0.7
+    idx = torch.randint(0, K, (n,))
+    if hot:
+        idx[: n - n // 8] = 3                      # one hot code
+    gl = torch.tensor([0.37])
+    g = torch.randn(n, D)
+    beta = 0.25
+    dxs, dEs = [], []
+    for _ in range(2):
+        dx, dE = N.vq_backward(dev(g), dev(gl), dev(x), dev(E), idx.cuda(), beta)
+        dxs.append(dx)
+        dEs.append(dE)
+    assert torch.equal(dEs[0], dEs[1]) and torch.equal(dxs[0], dxs[1])
+    nd = float(n * D)
+    diff = (E[idx] - x).double()
+    want_dE = torch.zeros(K, D, dtype=torch.float64).index_add_(0, idx, diff) * (0.37 * 2.0 / nd)
+    want_dx = g.double() - 0.37 * (2.0 * beta / nd) * diff
+    assert rel(dEs[0], want_dE) < 1e-5 and rel(dxs[0], want_dx) < 1e-6
+    base = torch.randn(K, D, device="cuda") * float(want_dE.abs().max())     # accumulate form (gradient sinks)
+    acc = base.clone()
+    N.vq_backward(None, dev(gl), dev(x), dev(E), idx.cuda(), beta, want_dx=False, dE_out=acc)
+    assert rel(acc.double() - base.double(), want_dE) < 1e-5
