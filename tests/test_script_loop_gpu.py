@@ -1,0 +1,133 @@
+"""The drop-in path as the reference's scripts drive it: plain ``model(x)`` + torch preprocessing + ``F.mse_loss`` +
+``loss.backward()`` + ``torch.optim.Adam(model.parameters())`` -- no Trainer, no flat buffers, no graph.
+
+The loop bodies below restate scripts/train_speech.py:62-74,88-91 and scripts/train_rir.py:42-58,72-75 statement by
+statement (torch ops on the GPU for ``abs`` / standardise / permute / MSE, exactly what the scripts execute); the same
+loop runs on the CPU oracle and the two loss trajectories and final parameters are compared.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vqvae_oracle as O  # noqa: E402
+
+
+def expand(p, R):
+    out = {}
+    for k, v in p.items():
+        if "_layers.0." in k:
+            for r in range(R):
+                out[k.replace("_layers.0.", "_layers.%d." % r)] = v
+        else:
+            out[k] = v
+    return out
+
+
+def build(cfg, p, **kw):
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    m = ConvolutionalVQVAE(*cfg, **kw)
+    m.load_state_dict(expand(p, cfg[3]))
+    return m.cuda()
+
+
+def speech_loop(model_fn, params, x_raw, steps, jitter_seed):
+    """train_speech.py:62-74, 88-91"""
+    opt = torch.optim.Adam(params, lr=1e-3, amsgrad=False)
+    np.random.seed(jitter_seed)
+    log = []
+    for i in range(steps):
+        x = torch.abs(x_raw[i])
+        x = (x - torch.mean(x, dim=1, keepdim=True)) / (torch.std(x, dim=1, keepdim=True) + 1e-8)
+        opt.zero_grad()
+        x = torch.squeeze(x, dim=1)
+        vq_loss, reconstructed_x, perplexity = model_fn(x)
+        if not x.shape == reconstructed_x.shape:
+            reduction = reconstructed_x.shape[2] - x.shape[2]
+            reconstructed_x = reconstructed_x[:, :, :-reduction]
+        recon_error = F.mse_loss(reconstructed_x, x, reduction="mean")
+        loss = recon_error + vq_loss
+        loss.backward()
+        opt.step()
+        log.append((recon_error.item(), vq_loss.item(), perplexity.item()))
+    return log
+
+
+def rir_loop(model_fn, params, rir_spec, wiener, steps):
+    """train_rir.py:42-58, 72-75 (jitter off, :137)"""
+    opt = torch.optim.Adam(params, lr=1e-3, amsgrad=False)
+    log = []
+    for i in range(steps):
+        x = rir_spec[i]
+        x = (x - torch.mean(x, dim=1, keepdim=True)) / (torch.std(x, dim=1, keepdim=True) + 1e-8)
+        x = torch.permute(x, [0, 2, 1])                       # NON-contiguous view, as in the script
+        w = wiener[i]
+        w = (w - torch.mean(w, dim=1, keepdim=True)) / (torch.std(w, dim=1, keepdim=True) + 1e-8)
+        w = torch.unsqueeze(w, 1)
+        opt.zero_grad()
+        vq_loss, reconstructed_x, perplexity = model_fn(x)
+        recon_error = F.mse_loss(reconstructed_x, w)
+        loss = recon_error + vq_loss
+        loss.backward()
+        opt.step()
+        log.append((recon_error.item(), vq_loss.item(), perplexity.item()))
+    return log
+
+
+def oracle_model(p, layers, use_jitter, beta=0.25):
+    def fn(x):
+        src = O.jitter_source_index(x.shape[2], 0.25) if use_jitter else None
+        out = O.vqvae_forward(x, p, layers, beta, src)
+        return out["vq_loss"], out["recon"], out["perplexity"]
+    return fn
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16x3", 2e-3)])
+def test_speech_script_loop_tracks_the_cpu_reference_path(dtype, tol):
+    from acoustic_locating_vq_vae import _ops
+    cfg = (20, 48, 8, 2, 24, 0.25, 64)          # in, H, D, R, RH, beta, K
+    shapes = O.vqvae_param_shapes(20, 48, 8, 24, 64)
+    p0 = O.closed_form_params(shapes, 0.8)
+    steps = 4
+    x_raw = [torch.from_numpy(O.hashed_uniform(3 * 20 * 33, 50 + i, 2.0).reshape(3, 20, 33)) for i in range(steps)]
+    p_cpu = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    want = speech_loop(oracle_model(p_cpu, cfg[3], True), list(p_cpu.values()), x_raw, steps, jitter_seed=11)
+    prev = _ops.get_compute_dtype()
+    _ops.set_compute_dtype(dtype)
+    try:
+        m = build(cfg, p0).train()
+        got = speech_loop(m, m.parameters(), [x.cuda() for x in x_raw], steps, jitter_seed=11)
+    finally:
+        _ops.set_compute_dtype(prev)
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            assert abs(a - b) <= tol * max(abs(b), 1e-3), (got, want)
+    sd = m.state_dict()
+    for k, v in p_cpu.items():
+        assert rel(sd[k], v.detach()) < 10 * tol, k
+
+
+def test_rir_script_loop_with_permuted_input_tracks_the_cpu_reference_path():
+    cfg = (33, 32, 6, 2, 8, 0.25, 16)           # in = frames (33), 1 output channel, jitter off
+    shapes = O.vqvae_param_shapes(33, 32, 6, 8, 16, out_channels=1)
+    p0 = O.closed_form_params(shapes, 0.8, gain=0.5)
+    steps = 3
+    rir = [torch.from_numpy(O.hashed_uniform(3 * 21 * 33, 70 + i, 2.0).reshape(3, 21, 33)) for i in range(steps)]
+    wien = [torch.from_numpy(O.hashed_uniform(3 * 21, 90 + i, 1.0).reshape(3, 21)) for i in range(steps)]
+    p_cpu = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    want = rir_loop(oracle_model(p_cpu, cfg[3], False), list(p_cpu.values()), rir, wien, steps)
+    m = build(cfg, p0, use_jitter=False, out_channels=1).train()
+    got = rir_loop(m, m.parameters(), [x.cuda() for x in rir], [w.cuda() for w in wien], steps)
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            assert abs(a - b) <= 2e-4 * max(abs(b), 1e-3), (got, want)
+    sd = m.state_dict()
+    for k, v in p_cpu.items():
+        assert rel(sd[k], v.detach()) < 2e-3, k
