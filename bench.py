@@ -244,6 +244,34 @@ def main():
                              "model_tflops": v2 * gf / 1e3, "launch": "eager"}
                 if summ2 is not None:
                     line[key]["roofline"] = roofline(summ2, mode, s2)
+    if rank == 0 and world == 1 and kind == "speech" and not args.no_f32_line:
+        # what scripts/train_speech.py itself gets when its imports resolve to this build: the script's own loop body
+        # (torch ops for |x| / standardise / MSE, loss.backward(), torch.optim.Adam) on the module API -- no
+        # Trainer, no flat buffers, no graph.  Same model config, batch and dtype; eager launches.
+        import torch.nn.functional as F
+        m2 = ConvolutionalVQVAE(*cfg).cuda().train()
+        opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3, amsgrad=False)
+
+        def script_step():
+            x = torch.abs(raw)
+            x = (x - torch.mean(x, dim=1, keepdim=True)) / (torch.std(x, dim=1, keepdim=True) + 1e-8)
+            opt2.zero_grad()
+            vq_loss, recon, _ = m2(x)
+            (F.mse_loss(recon, x, reduction="mean") + vq_loss).backward()
+            opt2.step()
+
+        for _ in range(3):
+            script_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s3 = max(3, min(10, args.steps))
+        for _ in range(s3):
+            script_step()
+        torch.cuda.synchronize()
+        e3 = time.perf_counter() - t0
+        line["script_loop_mode"] = {"value": B * s3 / e3, "unit": "spectrograms/s", "ms_per_step": 1e3 * e3 / s3, "steps": s3,
+                                    "launch": "eager, module API + torch.optim.Adam (train_speech.py:62-74,88-91)"}
+        del m2, opt2
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
