@@ -65,24 +65,22 @@ class ConvolutionalVQVAE(nn.Module):
         return self._vq.quantize(self._latent(x))
 
     def train_on_data(self, optimizer: optim, dataloader: DataLoader, num_training_updates, data_variance):
-        """The alternative loop the reference keeps on the class (convolutional_vq_vae.py:58-91)."""
+        """The alternative loop the reference keeps on the class (convolutional_vq_vae.py:58-91): a fresh loader
+        iterator per update, MSE scaled by 1/data_variance, a crop of one trailing frame when shapes differ, progress
+        printed every 100 updates, and the two history lists left on the instance."""
         self.train()
-        recon_log, perp_log = [], []
-        for i in range(num_training_updates):
-            (inputs, _) = next(iter(dataloader))
-            inputs = inputs.to(device)
+        history = {"recon": [], "perp": []}
+        for update in range(1, num_training_updates + 1):
+            batch = next(iter(dataloader))[0].to(device)
             optimizer.zero_grad()
-            vq_loss, data_recon, perplexity = self(inputs)
-            target = inputs if inputs.shape == data_recon.shape else inputs[:, :, :-1]
-            recon_error = F.mse_loss(data_recon, target) / data_variance
+            vq_loss, recon, perplexity = self(batch)
+            target = batch if batch.shape == recon.shape else batch[:, :, :-1]
+            recon_error = F.mse_loss(recon, target) / data_variance
             (recon_error + vq_loss).backward()
             optimizer.step()
-            recon_log.append(recon_error.item())
-            perp_log.append(perplexity.item())
-            if (i + 1) % 100 == 0:
-                print('%d iterations' % (i + 1))
-                print('recon_error: %.3f' % np.mean(recon_log[-100:]))
-                print('perplexity: %.3f' % np.mean(perp_log[-100:]))
-                print()
-        self.train_res_recon_error = recon_log
-        self.train_res_perplexity = perp_log
+            history["recon"].append(recon_error.item())
+            history["perp"].append(perplexity.item())
+            if update % 100 == 0:
+                print("%d iterations\nrecon_error: %.3f\nperplexity: %.3f\n"
+                      % (update, np.mean(history["recon"][-100:]), np.mean(history["perp"][-100:])))
+        self.train_res_recon_error, self.train_res_perplexity = history["recon"], history["perp"]
