@@ -51,6 +51,10 @@ _SIGNATURES = {
     "alvq_adam_advance_f32": (_i32, [_c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_void_p]),
     "alvq_stft_power_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_stft_power_f64": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_stft_complex_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_stft_complex_f64": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_fir_same_f64": (_i32, [_c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_spec_rir_wiener_f64": (_i32, [_c_void_p] * 7 + [_i32, _i32, _i32, _c_void_p]),
     "alvq_nlc_rows": (_i64, [_i32, _i32]),
     "alvq_nlc_channels": (_i32, [_i32]),
     "alvq_nlc_guard_rows": (_i32, []),
@@ -376,6 +380,53 @@ def stft_power(wave, n_fft=400, hop=160):
     else:
         _check(lib().alvq_stft_power_f32(_ptr(wave, name="wave"), _ptr(power), B, S, n_fft, hop, _stream()), "alvq_stft_power_f32")
     return power
+
+
+def stft_complex(wave, n_fft=400, hop=160):
+    """Complex STFT (B, n_fft/2+1, T) of (B,S) waveforms: complex64 for fp32 input, complex128 for fp64."""
+    B, S = wave.shape
+    F, T = n_fft // 2 + 1, 1 + S // hop
+    out = torch.empty((B, F, T, 2), device=wave.device, dtype=wave.dtype)
+    if wave.dtype == torch.float64:
+        _check(lib().alvq_stft_complex_f64(_ptr(wave, torch.float64, "wave"), _ptr(out, torch.float64), B, S, n_fft, hop,
+                                           _stream()), "alvq_stft_complex_f64")
+    else:
+        _check(lib().alvq_stft_complex_f32(_ptr(wave, name="wave"), _ptr(out), B, S, n_fft, hop, _stream()), "alvq_stft_complex_f32")
+    return torch.view_as_complex(out)
+
+
+def fir_same(wave, h):
+    """scipy.signal.convolve(wave, h, mode='same') in float64: wave (B,S) fp32, h (Nh,) or (B,Nh) fp64."""
+    B, S = wave.shape
+    if h.dim() == 1:
+        stride, Nh = 0, h.shape[0]
+    else:
+        if h.shape[0] != B:
+            raise RuntimeError("fir_same: %d impulse responses for %d waveforms" % (h.shape[0], B))
+        stride, Nh = h.shape[1], h.shape[1]
+    out = torch.empty((B, S), device=wave.device, dtype=torch.float64)
+    _check(lib().alvq_fir_same_f64(_ptr(wave, name="wave"), _ptr(h, torch.float64, "h"), _ptr(out, torch.float64), B, S, Nh,
+                                   stride, _stream()), "alvq_fir_same_f64")
+    return out
+
+
+def spec_rir_wiener(speech_spec, echoed_spec):
+    """complex64 S and complex128 E, both (B,F,T) -> (speech_pow fp32, echoed_pow fp64, rir_pow fp64, wiener (B,F) fp64)."""
+    if speech_spec.dtype != torch.complex64 or echoed_spec.dtype != torch.complex128 or speech_spec.shape != echoed_spec.shape:
+        raise RuntimeError("spec_rir_wiener: expected complex64 and complex128 tensors of one shape")
+    B, F, T = speech_spec.shape
+    dev = speech_spec.device
+    sr, er = torch.view_as_real(speech_spec), torch.view_as_real(echoed_spec)
+    speech_pow = torch.empty((B, F, T), device=dev, dtype=torch.float32)
+    echoed_pow = torch.empty((B, F, T), device=dev, dtype=torch.float64)
+    rir_pow = torch.empty((B, F, T), device=dev, dtype=torch.float64)
+    wiener = torch.empty((B, F), device=dev, dtype=torch.float64)
+    ws = torch.empty((B, F), device=dev, dtype=torch.float64)
+    _check(lib().alvq_spec_rir_wiener_f64(_ptr(sr, name="speech_spec"), _ptr(er, torch.float64, "echoed_spec"), _ptr(speech_pow),
+                                          _ptr(echoed_pow, torch.float64), _ptr(rir_pow, torch.float64),
+                                          _ptr(wiener, torch.float64), _ptr(ws, torch.float64), B, F, T, _stream()),
+           "alvq_spec_rir_wiener_f64")
+    return speech_pow, echoed_pow, rir_pow, wiener
 
 
 # ----------------------------------------------------------------------------------------------- bf16 path

@@ -166,6 +166,24 @@ int alvq_stft_power_f32(const float* wave, float* power, int B, int S, int n_fft
 /* float64 form: the reference's echoed signal is float64 (scipy convolve output, genereate_dataset.py:38-39). */
 int alvq_stft_power_f64(const double* wave, double* power, int B, int S, int n_fft, int hop, void* stream);
 
+/* The same transform keeping the phase: spec (B, n_fft/2+1, T) complex, stored as interleaved (re, im) pairs of the
+ * waveform's precision, divided by sqrt(sum(window^2)) (power=None, normalized=True). */
+int alvq_stft_complex_f32(const float* wave, float* spec, int B, int S, int n_fft, int hop, void* stream);
+int alvq_stft_complex_f64(const double* wave, double* spec, int B, int S, int n_fft, int hop, void* stream);
+
+/* scipy.signal.convolve(wave, h, mode="same") in float64 for a float32 waveform (B,S) and float64 impulse responses
+ * (genereate_dataset.py:38): out[b][i] = sum_j h[b][j] * wave[b][i + (Nh-1)/2 - j].  h_batch_stride: elements between
+ * consecutive impulse responses (0: one response shared by the batch).  Nh <= S. */
+int alvq_fir_same_f64(const float* wave, const double* h, double* out, int B, int S, int Nh, int h_batch_stride, void* stream);
+
+/* Dataset-generator arithmetic on the two complex STFTs (genereate_dataset.py:41-49), per batch item:
+ *   r = S / (E + 1e-8);  rir_pow = |r / max|r||^2;  wiener[f] = |sum_t E conj(S) / (sum_t S conj(S) + 1e-8)|^2;
+ *   speech_pow = |S|^2 (fp32);  echoed_pow = |E|^2 (fp64).
+ * speech_spec: complex64 (B,F,T) interleaved; echoed_spec: complex128 (B,F,T) interleaved; workspace: B*F doubles.
+ * All sums and the max run in a fixed order. */
+int alvq_spec_rir_wiener_f64(const float* speech_spec, const double* echoed_spec, float* speech_pow, double* echoed_pow,
+                             double* rir_pow, double* wiener, double* workspace, int B, int F, int T, void* stream);
+
 /* ================================================================================================
  * bf16 throughput path (BASELINE configs[1]: "batch=64 bf16").  Storage bf16, accumulation fp32.
  *
