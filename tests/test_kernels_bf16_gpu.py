@@ -28,7 +28,10 @@ def close_bf16(got, ref):
 
 SHAPES = [(2, 7, 16, 13, 3), (2, 16, 7, 13, 3), (2, 8, 16, 13, 1), (3, 5, 1, 201, 3), (2, 201, 1024, 500, 3),
           (2, 1024, 128, 500, 3), (2, 1024, 1024, 201, 1), (2, 500, 1024, 201, 3), (2, 192, 1024, 77, 3),
-          (2, 1024, 201, 500, 3), (5, 130, 130, 129, 3), (1, 64, 64, 1, 3)]
+          (2, 1024, 201, 500, 3), (5, 130, 130, 129, 3), (1, 64, 64, 1, 3),
+          # wide layers (256 x 256-tile kernels): the main 1024 -> 1024 width-3 shape, a ragged M inside the last m-tile
+          # (1000 of 1024, 480 of 512), ragged C, more rows than one tile and fewer
+          (2, 1024, 1024, 300, 3), (2, 96, 1000, 150, 3), (2, 64, 1000, 150, 1), (2, 70, 480, 90, 3), (3, 201, 2048, 40, 3)]
 
 
 def test_layout_roundtrip_and_zero_padding():
@@ -74,6 +77,26 @@ def test_conv_bf16_epilogue_fusions():
     cu = lambda t: N.ncl_to_nlc(t.cuda())
     y, y2 = N.conv1d_bf16(cu(x), N.pack_weight(w.cuda(), N.W_OIK), b.cuda(), cu(s1), cu(s2), cu(mk), cu(post), relu=True)
     assert close_bf16(y.to_ncl(), v) and close_bf16(y2.to_ncl(), v + bf(post))
+
+
+@pytest.mark.parametrize("M,KW", [(1024, 3), (1024, 1), (1000, 3), (480, 1)])
+def test_conv_bf16_epilogue_fusions_wide_layers(M, KW):
+    """The register-direct epilogue of the 256 x 256-tile kernels (permlane swap, 16-byte I/O): bias, two skips, ReLU,
+    ReLU-mask and the second output, on full and ragged last m-tiles."""
+    torch.manual_seed(21)
+    B, C, L = 3, 72, 140
+    x, w, b = torch.randn(B, C, L), torch.randn(M, C, KW) / (C * KW) ** 0.5, torch.randn(M)
+    s1, s2, mk, post = (torch.randn(B, M, L) for _ in range(4))
+    acc = F.conv1d(bf(x), bf(w), b, padding=KW // 2) + bf(s1) + bf(s2)
+    v = F.relu(acc)
+    v = torch.where(bf(mk) > 0, v, torch.zeros_like(v))
+    cu = lambda t: N.ncl_to_nlc(t.cuda())
+    y, y2 = N.conv1d_bf16(cu(x), N.pack_weight(w.cuda(), N.W_OIK), b.cuda(), cu(s1), cu(s2), cu(mk), cu(post), relu=True)
+    assert close_bf16(y.to_ncl(), v) and close_bf16(y2.to_ncl(), v + bf(post))
+    for out in (y, y2):                                                     # zero gap / tail rows and padded channels
+        mat = out.matrix().float().cpu()
+        assert float(mat[0].abs().sum()) == 0 and float(mat[L + 1].abs().sum()) == 0
+        assert float(mat[1 + B * (L + 1):].abs().sum()) == 0 and float(mat[:, M:].abs().sum()) == 0
 
 
 @pytest.mark.parametrize("B,C,M,L,KW", SHAPES)
