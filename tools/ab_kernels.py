@@ -1,4 +1,6 @@
-"""A/B two builds of libalvq.so on the same device in one process-sequence: interleaved rounds of bench_kernels."""
+"""A/B two builds of libalvq.so on the same device in one process-sequence: interleaved rounds of bench_kernels.
+Box-to-box spread (2-3 %) exceeds most kernel-level changes, so comparisons must share a device.  Keep a copy of the
+build to compare against as lib/libalvq_old.so (cp lib/libalvq.so lib/libalvq_old.so before editing a kernel)."""
 import os
 import subprocess
 import sys
@@ -7,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 libs = {"old": os.path.join(ROOT, "acoustic_locating_vq-vae_amd", "lib", "libalvq_old.so"),
         "new": os.path.join(ROOT, "acoustic_locating_vq-vae_amd", "lib", "libalvq.so")}
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+if not os.path.exists(libs["old"]):
+    raise SystemExit("no baseline build: cp %s %s first" % (libs["new"], libs["old"]))
 for r in range(rounds):
     for name, lib in libs.items():
         env = dict(os.environ, ALVQ_LIB=lib)
