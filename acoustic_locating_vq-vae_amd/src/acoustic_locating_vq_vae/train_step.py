@@ -248,6 +248,22 @@ class Trainer:
                     w.wait()                                   # stream-level wait: the Adam launch queues behind both
         self.opt.apply()                                       # one Adam launch over the flat buffer
 
+    # ------------------------------------------------------------------------------------------- checkpoint / resume
+    def state_dict(self):
+        """Everything a resumed run needs beyond ``model.state_dict()``: the Adam moments (flat, in parameter order)
+        and the step count.  The reference only ever saves the model (``torch.save(model, ...)``), so its resumed
+        runs restart Adam from zero; with this a resumed step is bitwise the step that would have come next."""
+        return {"model": self.model.state_dict(), "exp_avg": self.opt.exp_avg.clone(), "exp_avg_sq": self.opt.exp_avg_sq.clone(),
+                "step": self.opt.step_count, "numel": self.buffers.flat.numel(), "kind": self.kind}
+
+    def load_state_dict(self, state):
+        if state["numel"] != self.buffers.flat.numel() or state["kind"] != self.kind:
+            raise ValueError("checkpoint is for a different trainer (kind %s, %d flat elements)" % (state["kind"], state["numel"]))
+        self.model.load_state_dict(state["model"])           # copies INTO the flat-buffer views
+        self.opt.exp_avg.copy_(state["exp_avg"])
+        self.opt.exp_avg_sq.copy_(state["exp_avg_sq"])
+        self.opt.set_step(state["step"])
+
     def _jitters(self):
         from .vq_vae.modules.jitter import Jitter
         if not self.model.training:

@@ -345,3 +345,40 @@ def test_two_part_backward_equals_single_backward(dtype):
         _ops.set_compute_dtype(prev)
     assert torch.equal(finals["single"], finals["split"])
     assert torch.equal(finals["single"], finals["split+graph"])
+
+
+def test_trainer_checkpoint_resume_is_bitwise(tmp_path):
+    """Trainer.state_dict() / load_state_dict(): model + flat Adam moments + step count; a run resumed from the file
+    continues with exactly the parameters an uninterrupted run reaches."""
+    from acoustic_locating_vq_vae.train_step import Trainer
+    cfg = (20, 48, 8, 2, 24, 0.25, 64)
+    raws = [torch.randn(4, 20, 40, generator=torch.Generator().manual_seed(40 + s)).cuda() for s in range(5)]
+
+    def fresh():
+        torch.manual_seed(7)
+        m = build(cfg)
+        with torch.no_grad():
+            m._vq._embedding.weight.normal_(0, 0.7)
+        return Trainer(m.train(), "speech")
+
+    np.random.seed(5)
+    full = fresh()
+    for r in raws:
+        full.step(r)
+    np.random.seed(5)
+    first = fresh()
+    for r in raws[:3]:
+        first.step(r)
+    path = str(tmp_path / "trainer.pt")
+    torch.save(first.state_dict(), path)
+    rng = np.random.get_state()                      # the jitter stream is the caller's to carry over
+    resumed = fresh()
+    resumed.load_state_dict(torch.load(path))
+    assert resumed.opt.step_count == 3 and float(resumed.opt.scalars[3]) == 3.0
+    np.random.set_state(rng)
+    for r in raws[3:]:
+        resumed.step(r)
+    assert torch.equal(resumed.buffers.flat, full.buffers.flat)
+    assert torch.equal(resumed.opt.exp_avg_sq, full.opt.exp_avg_sq)
+    with pytest.raises(ValueError, match="different trainer"):
+        Trainer(build((20, 32, 8, 2, 24, 0.25, 64)).train(), "speech").load_state_dict(torch.load(path))
