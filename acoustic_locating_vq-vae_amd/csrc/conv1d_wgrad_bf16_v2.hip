@@ -7,7 +7,7 @@
 // a wave owns 64 m x (NCF*16) c for every tap: KW=3 -> NCF=2 (c-tile 128, 96 accumulator VGPRs),
 // KW=1 -> NCF=4 (c-tile 256, 64 accumulator VGPRs).  K-tile = 32 rows: a dY slab [32][128 m] (8 KB) and an X slab
 // [32 + halo][c-tile] staged ONCE and re-read at row offsets 0/1/2 by the taps.  Same 4-stage LDS-DMA ring and
-// counted-vmcnt / one-barrier-per-K-tile pipeline as conv1d_bf16_v2.hip.
+// counted-vmcnt pipeline as conv1d_bf16_v2.hip, with one barrier per PAIR of K-tiles.
 //
 // Bank conflicts: LDS rows are 256 B (or 512 B) = whole bank lines, so without care the 8 rows a half-wave reads
 // would hit the same banks.  The 32-B segment s of row r is stored at segment s ^ (r & 7) of its 256-B line
@@ -217,39 +217,45 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
 
   Raw r0, r1;
   Frags f0, f1;
+  // K-tiles are walked in PAIRS that share one barrier (a barrier per K-tile cost 9 % of this kernel: with 24 MFMAs
+  // per wave a K-tile is too short to amortise it).  Pair (t, t+1) lives in two of the four stages; at the barrier in
+  // the middle of the pair every wave has all of the pair's fragments in registers (the reads of tile t+1 are issued
+  // during tile t and drained before it) and has waited for the next pair's DMA, so after it the pair's two stages
+  // are free -- the DMA of the pair after next goes straight into them -- and the next pair is visible to everyone.
   if (n > 0) {
     issue(0);
     issue(1);
-    if (n > 2) issue(2);
-    wait_keep(n > 2 ? 2 : 1);
+    if (n > 2) {
+      issue(2);
+      issue(3);
+    }
+    wait_keep(n > 2 ? 2 : 0);
     __builtin_amdgcn_s_barrier();
     rd(r0, 0);
-    wait_keep(n > 2 ? 1 : 0);
     lgkm_drain();
-    __builtin_amdgcn_s_barrier();
     for (int t = 0; t < n; t += 2) {
-      // ---- even K-tile t (its reads sit in r0, complete)
+      // ---- first K-tile of the pair (its reads sit in r0, complete)
       join(f0, r0);
-      if (t + 3 < n) issue((t + 3) & 3);
       mm(f0, 0);
       __builtin_amdgcn_sched_barrier(0);
       rd(r1, (t + 1) & 3);
       __builtin_amdgcn_sched_barrier(0);
       mm(f0, 1);
-      wait_keep(t + 3 < n ? 1 : 0);
+      if (t + 2 < n) wait_keep(0);         // the next pair (issued two K-tiles ago) has landed
       lgkm_drain();                        // r1 landed (issued 12+ MFMAs ago)
       __builtin_amdgcn_s_barrier();
-      // ---- odd K-tile t+1
+      // ---- second K-tile
+      if (t + 4 < n) {
+        issue((t + 4) & 3);
+        issue((t + 5) & 3);
+      }
       join(f1, r1);
-      if (t + 4 < n) issue((t + 4) & 3);
       mm(f1, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (t + 2 < n) rd(r0, (t + 2) & 3);
       __builtin_amdgcn_sched_barrier(0);
       mm(f1, 1);
-      wait_keep(t + 4 < n ? 1 : 0);
       lgkm_drain();
-      __builtin_amdgcn_s_barrier();
     }
   }
 
