@@ -29,12 +29,48 @@ struct FragSet {
 //     time, 37 % of a width-1 tile's.
 //   OUT == 1 (fp32 NCL, bias only; rare at this tile size): four 64-row slabs through an fp32 LDS tile so that lanes
 //     run along l.  All waves must have finished reading the operand stages before the call.
+// The register-direct bf16 epilogue of one wave's 128 (m) x 64 (rows) block: rows r0 + wn0 .., channels m0 + wm0 ..
+__device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[8][4], int m0, int r0, int li, int kq,
+                                                   int wm0, int wn0);
+
 template <int OUT>
 __device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4 (&acc)[8][4], unsigned char* lds, int m0,
                                                  int r0, int wave, int tid, int li, int kq, int wm0) {
   if (OUT == 0) {
+    wave_epilogue_bf16(a, acc, m0, r0, li, kq, wm0, (wave & 3) * 64);
+    return;
+  }
+  // OUT == 1: NCL fp32 (bias only) -- lane = row (coalesced along l), loop over channels
+  float* Cs = (float*)lds;
+  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  for (int slab = 0; slab < 4; ++slab) {
+    if ((wave & 3) == slab) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int rl = ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
+          *(f32x4*)(Cs + rl * V2_CS + ml) = acc[mi][ni];
+        }
+    }
+    __syncthreads();
+    const int rl = tid & 63, row = r0 + slab * 64 + rl;
+    int b, l;
+    if (row_valid(row, Lp1, ndata, &b, &l)) {
+      for (int ml = tid >> 6; ml < V2_M; ml += 8) {
+        const int m = m0 + ml;
+        if (m >= a.M) break;
+        a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * V2_CS + ml] + (a.bias ? a.bias[m] : 0.f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[8][4], int m0, int r0, int li, int kq,
+                                                   int wm0, int wn0) {
+  {
     const int Lp1 = a.L + 1, ndata = a.B * Lp1;
-    const int wn0 = (wave & 3) * 64;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int row = r0 + wn0 + ni * 16 + li;
@@ -60,58 +96,6 @@ __device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4
         epilogue_store8(a, v, bv, ok, ro + mb);
       }
     }
-    return;
-  }
-  float* Cs = (float*)lds;
-  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
-  for (int slab = 0; slab < 4; ++slab) {
-    if ((wave & 3) == slab) {
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int rl = ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
-          *(f32x4*)(Cs + rl * V2_CS + ml) = acc[mi][ni];
-        }
-    }
-    __syncthreads();
-    if (OUT == 0) {
-      // thread = 8 consecutive channels of one row; 32 threads per row, 16 rows per pass, 4 passes
-      const int tx = tid & 31, ty = tid >> 5;
-      const int mbase = m0 + tx * 8;
-      if (mbase < a.Mop) {
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && mbase + e < a.M) ? a.bias[mbase + e] : 0.f;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int rl = pass * 16 + ty, row = r0 + slab * 64 + rl;
-          int b, l;
-          const bool ok = row_valid(row, Lp1, ndata, &b, &l);
-          const long o = (long)row * a.Mop + mbase;
-          float v[8];
-          const f32x4 c0 = *(const f32x4*)(Cs + rl * V2_CS + tx * 8), c1 = *(const f32x4*)(Cs + rl * V2_CS + tx * 8 + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = c0[e];
-            v[e + 4] = c1[e];
-          }
-          epilogue_store8(a, v, bv, ok, o);
-        }
-      }
-    } else {
-      // NCL fp32 (bias only): lane = row (coalesced along l), loop over channels
-      const int rl = tid & 63, row = r0 + slab * 64 + rl;
-      int b, l;
-      if (row_valid(row, Lp1, ndata, &b, &l)) {
-        for (int ml = tid >> 6; ml < V2_M; ml += 8) {
-          const int m = m0 + ml;
-          if (m >= a.M) break;
-          a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * V2_CS + ml] + (a.bias ? a.bias[m] : 0.f);
-        }
-      }
-    }
-    __syncthreads();
   }
 }
 
