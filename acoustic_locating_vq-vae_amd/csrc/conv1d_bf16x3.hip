@@ -38,6 +38,76 @@ __device__ __forceinline__ void split2(float v, u16& hi, u16& lo) {
   lo = f2bf(v - bf2f(hi));
 }
 
+// 8 consecutive channels of one row: two 16-byte stores per output (hi and lo plane), hardware bf16 rounding
+__device__ __forceinline__ void split_store8(u16* p, long plane, long o, const float (&v)[8]) {
+  u32x4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
+    lo[e] = f2bf_pk(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
+  }
+  *(u32x4*)(p + o) = hi;
+  *(u32x4*)(p + plane + o) = lo;
+}
+__device__ __forceinline__ void split_load_add8(const u16* p, long plane, long o, float (&v)[8]) {
+  const u16x8 sh = *(const u16x8*)(p + o), sl = *(const u16x8*)(p + plane + o);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] += bf2f(sh[e]) + bf2f(sl[e]);
+}
+
+// Register-direct epilogue of one wave's 128 (m) x 64 (rows) block, split-bf16 flavour of wave_epilogue_bf16
+// (conv1d_bf16_tile256.h): v_permlane16_swap gives every lane 8 consecutive channels, 16-byte loads and stores.
+__device__ __forceinline__ void wave_epilogue_x3(const ConvX3Args& ax, const f32x4 (&acc)[8][4], int m0, int r0, int li,
+                                                 int kq, int wm0, int wn0) {
+  const ConvBArgs& a = ax.b;
+  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int row = r0 + wn0 + ni * 16 + li;
+    int b, l;
+    const bool ok = row_valid(row, Lp1, ndata, &b, &l);
+    const long ro = (long)row * a.Mop;
+#pragma unroll
+    for (int mp = 0; mp < 8; mp += 2) {
+      if (m0 + wm0 + mp * 16 >= a.Mop) continue;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mp][ni][e]), __float_as_uint(acc[mp + 1][ni][e]),
+                                                         false, false);
+        v[e] = __uint_as_float(r[0]);
+        v[e + 4] = __uint_as_float(r[1]);
+      }
+      const int mb = m0 + wm0 + (mp + (kq & 1)) * 16 + (kq >> 1) * 8;
+      const long o = ro + mb;
+      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (!ok) {                                           // gap / tail rows stay zero in both planes
+        split_store8(a.y, ax.y_plane, o, z);
+        if (a.y2) split_store8(a.y2, ax.y_plane, o, z);
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (a.bias && mb + e < a.M) ? a.bias[mb + e] : 0.f;
+      if (a.skip1) split_load_add8(a.skip1, ax.y_plane, o, v);
+      if (a.skip2) split_load_add8(a.skip2, ax.y_plane, o, v);
+      if (a.relu & 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (a.mask) {   // sign of a split value is the sign of its hi plane
+        const u16x8 s = *(const u16x8*)(a.mask + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
+      }
+      split_store8(a.y, ax.y_plane, o, v);
+      if (a.y2) {
+        split_load_add8(a.post, ax.y_plane, o, v);
+        split_store8(a.y2, ax.y_plane, o, v);
+      }
+    }
+  }
+}
+
 template <int OUT>
 __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, int KW) {
   const ConvBArgs& a = ax.b;
@@ -130,7 +200,11 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, in
     __builtin_amdgcn_s_barrier();
   }
 
-  // ---- epilogue: four 64-row slabs through an fp32 LDS tile
+  if (OUT == 0) {   // bf16 hi + lo planes, straight from the accumulators
+    wave_epilogue_x3(ax, acc, m0, r0, li, kq, wm0, wn0);
+    return;
+  }
+  // ---- OUT == 1 (fp32 NCL, bias only): four 64-row slabs through an fp32 LDS tile
   float* Cs = (float*)lds;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   for (int slab = 0; slab < 4; ++slab) {
@@ -144,74 +218,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, in
         }
     }
     __syncthreads();
-    if (OUT == 0) {
-      const int tx = tid & 31, ty = tid >> 5;
-      const int mbase = m0 + tx * 8;
-      if (mbase < a.Mop) {
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && mbase + e < a.M) ? a.bias[mbase + e] : 0.f;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int rl = pass * 16 + ty, row = r0 + slab * 64 + rl;
-          int b, l;
-          const bool ok = row_valid(row, Lp1, ndata, &b, &l);
-          const long o = (long)row * a.Mop + mbase;
-          u16x8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = oh, o2h = oh, o2l = oh;
-          if (ok) {
-            float v[8];
-            const f32x4 c0 = *(const f32x4*)(Cs + rl * X3_CS + tx * 8), c1 = *(const f32x4*)(Cs + rl * X3_CS + tx * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = c0[e] + bv[e];
-              v[e + 4] = c1[e] + bv[e + 4];
-            }
-            if (a.skip1) {
-              const u16x8 sh = *(const u16x8*)(a.skip1 + o), sl = *(const u16x8*)(a.skip1 + ax.y_plane + o);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += bf2f(sh[e]) + bf2f(sl[e]);
-            }
-            if (a.skip2) {
-              const u16x8 sh = *(const u16x8*)(a.skip2 + o), sl = *(const u16x8*)(a.skip2 + ax.y_plane + o);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += bf2f(sh[e]) + bf2f(sl[e]);
-            }
-            if (a.relu & 1) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (a.mask) {   // sign of a split value is the sign of its hi plane
-              const u16x8 s = *(const u16x8*)(a.mask + o);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              u16 h, l2;
-              split2(v[e], h, l2);
-              oh[e] = h;
-              ol[e] = l2;
-            }
-            if (a.y2) {
-              const u16x8 sh = *(const u16x8*)(a.post + o), sl = *(const u16x8*)(a.post + ax.y_plane + o);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                u16 h, l2;
-                split2(v[e] + (bf2f(sh[e]) + bf2f(sl[e])), h, l2);
-                o2h[e] = h;
-                o2l[e] = l2;
-              }
-            }
-          }
-          *(u16x8*)(a.y + o) = oh;
-          *(u16x8*)(a.y + ax.y_plane + o) = ol;
-          if (a.y2) {
-            *(u16x8*)(a.y2 + o) = o2h;
-            *(u16x8*)(a.y2 + ax.y_plane + o) = o2l;
-          }
-        }
-      }
-    } else {
+    {
       const int rl = tid & 63, row = r0 + slab * 64 + rl;
       int b, l;
       if (row_valid(row, Lp1, ndata, &b, &l)) {
