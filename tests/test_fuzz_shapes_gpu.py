@@ -1,0 +1,72 @@
+"""Seeded shape fuzz: 40 random (B, C, M, L, KW) problems per precision through forward, data-gradient and
+weight-gradient, against torch's CPU convolution on operands rounded to what the kernels store.  Shapes are drawn to
+straddle every dispatch boundary (narrow / 256-tile kernels, ragged channel counts, single-row problems, several row
+tiles, M within and beyond the last m-tile)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from acoustic_locating_vq_vae import _native as N  # noqa: E402
+
+
+def draw(rng):
+    C = int(rng.choice([1, 3, 7, 20, 64, 65, 130, 201, 256, 500]))
+    M = int(rng.choice([1, 5, 64, 100, 128, 201, 230, 256, 300, 480, 512, 1000]))
+    return int(rng.integers(1, 5)), C, M, int(rng.choice([1, 2, 13, 77, 201, 340])), int(rng.choice([1, 3]))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+CASES = [draw(np.random.default_rng(1000 + i)) for i in range(40)]
+
+
+@pytest.mark.parametrize("B,C,M,L,KW", CASES)
+def test_fuzz_f32(B, C, M, L, KW):
+    g = torch.Generator().manual_seed(B * 7919 + C * 31 + M * 17 + L * 3 + KW)
+    x = torch.randn(B, C, L, generator=g).requires_grad_(True)
+    w = (torch.randn(M, C, KW, generator=g) / (C * KW) ** 0.5).requires_grad_(True)
+    b = torch.randn(M, generator=g, requires_grad=True)
+    dy = torch.randn(B, M, L, generator=g)
+    y = F.conv1d(x, w, b, padding=KW // 2)
+    y.backward(dy)
+    xd, wd, bd, dyd = x.detach().cuda(), w.detach().cuda(), b.detach().cuda(), dy.cuda()
+    assert rel(N.conv1d(xd, wd, bd), y) < 2e-5
+    assert rel(N.conv1d(dyd, wd, w_layout=N.W_IOK), x.grad) < 2e-5
+    dw, db = N.conv1d_wgrad(dyd, xd, KW, want_bias=True)
+    assert rel(dw, w.grad) < 5e-5 and rel(db, b.grad) < 5e-5 + 1e-6 * float(dy.abs().sum()) / (float(b.grad.abs().max()) + 1e-30)
+
+
+@pytest.mark.parametrize("planes,tol", [(1, 3e-5), (2, 6e-5)])
+@pytest.mark.parametrize("B,C,M,L,KW", CASES)
+def test_fuzz_bf16(B, C, M, L, KW, planes, tol):
+    g = torch.Generator().manual_seed(B * 7919 + C * 31 + M * 17 + L * 3 + KW + planes)
+    rnd = (lambda t: t.bfloat16().float()) if planes == 1 else (lambda t: t)
+    x = rnd(torch.randn(B, C, L, generator=g)).requires_grad_(True)
+    w = rnd(torch.randn(M, C, KW, generator=g) / (C * KW) ** 0.5).requires_grad_(True)
+    b = torch.randn(M, generator=g, requires_grad=True)
+    dy = rnd(torch.randn(B, M, L, generator=g))
+    y = F.conv1d(x, w, b, padding=KW // 2)
+    y.backward(dy)
+    xn, dyn = N.ncl_to_nlc(x.detach().cuda(), planes), N.ncl_to_nlc(dy.cuda(), planes)
+    wd = w.detach().cuda()
+    assert rel(N.conv1d_bf16(xn, N.pack_weight(wd, N.W_OIK, planes), b.detach().cuda(), out_ncl=True), y) < tol
+    assert rel(N.conv1d_bf16(dyn, N.pack_weight(wd, N.W_IOK, planes), out_ncl=True), x.grad) < tol
+    dw, db = N.conv1d_wgrad_bf16(dyn, xn, KW, want_bias=True)
+    assert rel(dw, w.grad) < 2 * tol
+    # column sums of dy as stored: exact bf16 values (planes = 1) or hi + lo pairs carrying 2^-17 of each element
+    assert float((db.cpu() - b.grad).abs().max()) <= (2e-6 if planes == 1 else 2e-5) * float(dy.abs().sum(dim=(0, 2)).max()) + 1e-30
+    # the bf16 NLC output keeps its gap / tail rows and padded channels at zero for any shape
+    out = N.conv1d_bf16(xn, N.pack_weight(wd, N.W_OIK, planes), b.detach().cuda(), relu=True)
+    mat = out.storage.view(out.planes, -1, out.Cp)[:, out.guard:out.guard + out.rows].float()
+    gaps = torch.arange(0, B * (L + 1) + 1, L + 1, device="cuda")
+    assert float(mat[:, gaps].abs().max()) == 0.0
+    if B * (L + 1) + 1 < out.rows:
+        assert float(mat[:, B * (L + 1) + 1:].abs().max()) == 0.0
+    if M < out.Cp:
+        assert float(mat[:, :, M:].abs().max()) == 0.0
