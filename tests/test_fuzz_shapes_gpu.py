@@ -70,3 +70,35 @@ def test_fuzz_bf16(B, C, M, L, KW, planes, tol):
         assert float(mat[:, B * (L + 1) + 1:].abs().max()) == 0.0
     if M < out.Cp:
         assert float(mat[:, :, M:].abs().max()) == 0.0
+
+
+VQ_CASES = [(int(r.choice([1, 63, 64, 65, 777, 4097])), int(r.choice([1, 2, 16, 100, 513, 1024])),
+             int(r.choice([1, 4, 31, 64, 100, 128, 200, 256, 300, 512])))
+            for r in (np.random.default_rng(2000 + i) for i in range(30))]
+
+
+@pytest.mark.parametrize("n,K,D", VQ_CASES)
+def test_fuzz_vq(n, K, D):
+    """Nearest-code search, gather/loss and backward on random (rows, codes, dims): the chosen code's distance (the
+    reference's fl(fl(|x|^2 + |e|^2) - 2 x.e) arithmetic, CPU oracle) is the row minimum or within 2 ulp of it, ties go
+    to the lowest index, and the quantiser's loss / gradients match the oracle."""
+    from oracle import vqvae_oracle as O
+    g = torch.Generator().manual_seed(n * 31 + K * 7 + D)
+    x, e = torch.randn(n, D, generator=g), torch.randn(K, D, generator=g) * 0.8
+    d = O.vq_distances(x, e)
+    ref = torch.argmin(d, dim=1)
+    got = N.vq_argmin(x.cuda(), e.cuda()).cpu()
+    for r in (got != ref).nonzero().view(-1).tolist():
+        dm, dg = d[r, ref[r]], d[r, got[r]]
+        ulp = float(torch.nextafter(dm.abs(), torch.tensor(float("inf"))) - dm.abs())
+        assert float(dg - dm) <= 2 * ulp, (r, float(dm), float(dg))
+    assert int((got != ref).sum()) <= max(1, n // 500)
+    q_st, out = N.vq_gather_loss(x.cuda(), e.cuda(), got.cuda(), 0.25)
+    m = float(((e[got] - x) ** 2).double().mean())
+    assert abs(float(out[0]) - 1.25 * m) <= 1e-5 * 1.25 * m + 1e-12
+    gq, gl = torch.randn(n, D, generator=g), torch.tensor([0.7])
+    dx, dE = N.vq_backward(gq.cuda(), gl.cuda(), x.cuda(), e.cuda(), got.cuda(), 0.25)
+    diff = (e[got] - x).double()
+    want_dx = gq.double() - 0.7 * (2 * 0.25 / (n * D)) * diff
+    want_dE = torch.zeros(K, D, dtype=torch.float64).index_add_(0, got, diff) * (0.7 * 2.0 / (n * D))
+    assert rel(dx, want_dx) < 1e-6 and rel(dE, want_dE) < 1e-5
