@@ -393,8 +393,9 @@ extern "C" int alvq_vq_argmin_f32(const float* x, const float* codebook, int64_t
     (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  // 8 waves (128 rows) when the stationary block of a 4-wave workgroup would leave one wave per SIMD
-  const bool wide = D > 128 && (size_t)(128 * XSTR + VQ_CT * VQ_ES) * sizeof(float) <= 160 * 1024;
+  // 8 waves (128 rows) from D = 128 up: a 4-wave workgroup would leave one wave per SIMD there, and 128-row blocks
+  // halve the codebook-tile traffic per row (+7 % at the speech size)
+  const bool wide = D >= 128 && (size_t)(128 * XSTR + VQ_CT * VQ_ES) * sizeof(float) <= 160 * 1024;
   const int rb = wide ? 128 : 64;
   const size_t lds = (size_t)(rb * XSTR + VQ_CT * VQ_ES) * sizeof(float);
   const dim3 grid((unsigned)((N + rb - 1) / rb));
