@@ -17,8 +17,12 @@ for key in sorted(agg):
     c = {k: v[1] / v[0] for k, v in agg[key].items()}
     print("%-36s grid %-8s" % key)
     print("   " + "  ".join("%s=%.4g" % (k, v) for k, v in sorted(c.items())))
-    if "SQ_BUSY_CYCLES" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-        print("   mfma_busy/busy_cycles(per SE sum) = %.3f" % (c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c["SQ_BUSY_CYCLES"], 1)))
+    if "GRBM_GUI_ACTIVE" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        # MFMA_BUSY sums the matrix-pipe busy cycles of all 1024 SIMDs (= 16 per 16x16x32 bf16 MFMA);
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' active cycles, so /8 is the kernel's length in shader cycles
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        print("   kernel length %.0f cycles; matrix-pipe utilisation = MFMA_BUSY / (cycles x 1024 SIMDs) = %.3f"
+              % (cyc, c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)))
     if "SQ_WAVE_CYCLES" in c:
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS",
                   "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM"):
