@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void relu_mask_bf16_kernel(const u16* dy, cons
 using namespace alvq;
 
 static inline int pad_to(int x, int q) { return (x + q - 1) / q * q; }
+constexpr long ALVQ_WIDE_MIN_TILES = 192;   // 256 x 256-tile kernels need about one workgroup per CU to pay off
 
 extern "C" int64_t alvq_nlc_rows(int B, int L) { return (B <= 0 || L <= 0) ? -1 : (int64_t)pad_to(1 + B * (L + 1), NLC_ROW_PAD); }
 extern "C" int alvq_nlc_channels(int C) { return C <= 0 ? -1 : pad_to(C, TB_K); }
@@ -295,7 +296,13 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
   static int use_v2 = -1, use_k3 = -1;
   if (use_v2 < 0) use_v2 = getenv("ALVQ_CONV_V2") ? atoi(getenv("ALVQ_CONV_V2")) : 1;
   if (use_k3 < 0) use_k3 = getenv("ALVQ_CONV_K3") ? atoi(getenv("ALVQ_CONV_K3")) : 1;
-  if (use_v2 && pad_to(M, 256) - M <= 32) return (KW == 3 && use_k3) ? conv1d_bf16_k3_launch(a, s) : conv1d_bf16_v2_launch(a, KW, s);
+  // ... and only when that gives every CU a workgroup: a small problem (the RIR config: 26 row tiles x 4 m-tiles = 104
+  // workgroups of 256 x 256 for 256 CUs) is better served by four times as many 128 x 128 tiles at two per CU
+  const long tiles256 = (alvq_nlc_rows(B, L) / 256) * (pad_to(M, 256) / 256);
+  static long min_tiles = -1;      // ALVQ_WIDE_MIN_TILES=1 lets the unit tests drive the wide kernels with small problems
+  if (min_tiles < 0) min_tiles = getenv("ALVQ_WIDE_MIN_TILES") ? atol(getenv("ALVQ_WIDE_MIN_TILES")) : ALVQ_WIDE_MIN_TILES;
+  if (use_v2 && pad_to(M, 256) - M <= 32 && tiles256 >= min_tiles)
+    return (KW == 3 && use_k3) ? conv1d_bf16_k3_launch(a, s) : conv1d_bf16_v2_launch(a, KW, s);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -583,7 +583,8 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
         family, fn = "conv1d_bf16x3_kernel", lib().alvq_conv1d_bf16x3
     else:
         # mirrors the dispatch in csrc/conv1d_bf16.hip: wide layers go to the 256x256-tile kernels (k3 for width 3)
-        wide = ((M + 255) // 256 * 256 - M) <= 32
+        min_tiles = int(os.environ.get("ALVQ_WIDE_MIN_TILES", "192"))
+        wide = ((M + 255) // 256 * 256 - M) <= 32 and (x.rows // 256) * ((M + 255) // 256) >= min_tiles
         family = ("conv1d_bf16_k3_kernel" if KW == 3 else "conv1d_bf16_v2_kernel") if wide else "conv1d_bf16_kernel"
         fn = lib().alvq_conv1d_bf16
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
