@@ -224,7 +224,7 @@ class OracleTrainer:
         loss = recon_error + out["vq_loss"]
         loss.backward()
         self.opt.step()
-        return float(loss), float(recon_error), float(out["perplexity"])
+        return float(loss.detach()), float(recon_error.detach()), float(out["perplexity"].detach())
 
 
 # --------------------------------------------------------------------------- exactly reproducible fills
