@@ -1,6 +1,6 @@
 """Utterances/s of the waveform front end: the dataset generator's per-sample arithmetic
 (genereate_dataset.py:35-49) for 5 s utterances at 16 kHz with a 0.4 s impulse response, HIP kernels vs the CPU
-restatement (scipy + torch.stft) on the host cores.    python tools/bench_front_end.py [batch=64]"""
+restatement (scipy + torch.stft) on the host cores.    python tests/bench_front_end.py [batch=64]"""
 import json
 import os
 import sys

@@ -4,7 +4,7 @@
                         then ``.to(device)`` (scripts/train_speech.py:59-62), restated here;
   DeviceLoader       -- streaming (thread pool + pinned staging + copy stream) and resident (samples parked in HBM).
 
-    python tools/bench_loader.py [n_samples=256] [batch=64]
+    python tests/bench_loader.py [n_samples=256] [batch=64]
 """
 import json
 import os
