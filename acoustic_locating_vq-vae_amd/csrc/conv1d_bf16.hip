@@ -23,6 +23,7 @@
 
 #include "alvq_common.h"
 #include "bf16_common.h"
+#include "conv1d_bf16_tile256.h"
 
 namespace alvq {
 
@@ -117,7 +118,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
     chunk = nchunk;
   }
 
-  // ---- epilogue 1: D[i = m][j = row] -> fp32 C tile Cs[row][m] (4 consecutive m per lane = one 16-B write)
+  if (OUT == 0) {   // NLC bf16: straight from the accumulators (conv1d_bf16_tile256.h)
+    wave_epilogue_bf16<4, 4>(a, acc, m0, r0, li, kq, wm0, wn0);
+    return;
+  }
+  // ---- OUT == 1, step 1: D[i = m][j = row] -> fp32 C tile Cs[row][m] (4 consecutive m per lane = one 16-B write)
   float* Cs = (float*)lds;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -129,32 +134,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
   __syncthreads();
 
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
-  if (OUT == 0) {
-    // ---- epilogue 2 (NLC bf16): thread = 8 consecutive channels of one row; 16 rows per pass
-    const int tx = tid & 15, ty = tid >> 4;
-    const int mbase = m0 + tx * 8;
-    if (mbase < a.Mop) {
-      float bv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = (a.bias && mbase + e < a.M) ? a.bias[mbase + e] : 0.f;
-#pragma unroll
-      for (int pass = 0; pass < 8; ++pass) {
-        const int rl = pass * 16 + ty, row = r0 + rl;
-        int b, l;
-        const bool ok = row_valid(row, Lp1, ndata, &b, &l);
-        const long o = (long)row * a.Mop + mbase;
-        float v[8];
-        const f32x4 c0 = *(const f32x4*)(Cs + rl * CS + tx * 8), c1 = *(const f32x4*)(Cs + rl * CS + tx * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = c0[e];
-          v[e + 4] = c1[e];
-        }
-        epilogue_store8(a, v, bv, ok, o);
-      }
-    }
-  } else {
-    // ---- epilogue 2 (NCL fp32, bias only): lane = row (coalesced along l), loop over channels
+  {
+    // ---- step 2 (NCL fp32, bias only): lane = row (coalesced along l), loop over channels
     const int rl = tid & 127, row = r0 + rl;
     int b, l;
     const bool ok = row_valid(row, Lp1, ndata, &b, &l);

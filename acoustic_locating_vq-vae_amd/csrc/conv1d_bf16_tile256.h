@@ -29,9 +29,11 @@ struct FragSet {
 //     time, 37 % of a width-1 tile's.
 //   OUT == 1 (fp32 NCL, bias only; rare at this tile size): four 64-row slabs through an fp32 LDS tile so that lanes
 //     run along l.  All waves must have finished reading the operand stages before the call.
-// The register-direct bf16 epilogue of one wave's 128 (m) x 64 (rows) block: rows r0 + wn0 .., channels m0 + wm0 ..
-__device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[8][4], int m0, int r0, int li, int kq,
-                                                   int wm0, int wn0);
+// The register-direct bf16 epilogue of one wave's (NMI*16) m x (NNI*16) rows block of MFMA fragments:
+// rows r0 + wn0 .., channels m0 + wm0 ..   (NMI even: fragments are swapped in pairs)
+template <int NMI, int NNI>
+__device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[NMI][NNI], int m0, int r0, int li,
+                                                   int kq, int wm0, int wn0);
 
 template <int OUT>
 __device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4 (&acc)[8][4], unsigned char* lds, int m0,
@@ -67,18 +69,20 @@ __device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4
   }
 }
 
-__device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[8][4], int m0, int r0, int li, int kq,
-                                                   int wm0, int wn0) {
+template <int NMI, int NNI>
+__device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[NMI][NNI], int m0, int r0, int li,
+                                                   int kq, int wm0, int wn0) {
+  static_assert(NMI % 2 == 0, "fragments are swapped in pairs");
   {
     const int Lp1 = a.L + 1, ndata = a.B * Lp1;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NNI; ++ni) {
       const int row = r0 + wn0 + ni * 16 + li;
       int b, l;
       const bool ok = row_valid(row, Lp1, ndata, &b, &l);
       const long ro = (long)row * a.Mop;
 #pragma unroll
-      for (int mp = 0; mp < 8; mp += 2) {
+      for (int mp = 0; mp < NMI; mp += 2) {
         if (m0 + wm0 + mp * 16 >= a.Mop) continue;      // Mop % 64 == 0 and the pair starts on a multiple of 32
         float v[8];
 #pragma unroll
