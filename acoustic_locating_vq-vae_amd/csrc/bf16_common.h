@@ -56,6 +56,10 @@ struct ConvBArgs {
   int B, L, Cp, M, Mop, Mp128;   // Mop: output row stride (M rounded to 64); Mp128: packed-weight rows per tap
   int relu;
   int rtiles, mtiles;
+  // sign bits of activations, one byte per 8 consecutive channels of a row ([rows][Mop/8]): a ReLU'd output can leave
+  // its mask behind (bits_out), and a later data-gradient launch reads 1/16 of the bytes instead of the tensor (mask_bits)
+  const unsigned char* mask_bits;
+  unsigned char* bits_out;
 };
 
 constexpr int WP_ROWS = 256;   // packed weights are padded to this many rows per tap (largest m-tile)
@@ -94,7 +98,11 @@ __device__ __forceinline__ void epilogue_store8(const ConvBArgs& a, float (&v)[8
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    if (a.mask) {
+    if (a.mask_bits) {
+      const unsigned bt = a.mask_bits[o >> 3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((bt >> e) & 1u) ? v[e] : 0.f;
+    } else if (a.mask) {
       const u16x8 s = *(const u16x8*)(a.mask + o);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
@@ -109,6 +117,16 @@ __device__ __forceinline__ void epilogue_store8(const ConvBArgs& a, float (&v)[8
   }
   *(u32x4*)(a.y + o) = out;
   if (a.y2) *(u32x4*)(a.y2 + o) = out2;
+  if (a.bits_out) {   // bit e = (stored y[e] > 0); zero for gap / tail rows
+    unsigned bt = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned w = out[e];
+      bt |= (((w & 0x8000u) == 0 && (w & 0x7fffu) != 0) ? 1u : 0u) << (2 * e);
+      bt |= (((w & 0x80000000u) == 0 && (w & 0x7fff0000u) != 0) ? 1u : 0u) << (2 * e + 1);
+    }
+    a.bits_out[o >> 3] = (unsigned char)bt;
+  }
 }
 
 // defined in conv1d_bf16_v2.hip: the 256x256-tile kernel for wide layers

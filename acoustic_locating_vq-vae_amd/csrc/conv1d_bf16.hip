@@ -256,7 +256,7 @@ extern "C" int alvq_relu_mask_bf16(const void* dy, const void* t, void* out, int
 
 extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
                                 const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M,
-                                int L, int KW, int relu, void* stream) {
+                                int L, int KW, int relu, const void* mask_bits, void* relu_bits_out, void* stream) {
   ALVQ_REQUIRE(x && wp && (y || y_ncl), ALVQ_EINVAL, "alvq_conv1d_bf16: null x/wp/y");
   ALVQ_REQUIRE(!(y && y_ncl), ALVQ_EINVAL, "alvq_conv1d_bf16: choose one of y (NLC bf16) and y_ncl (NCL fp32)");
   ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_bf16: bad dims");
@@ -267,7 +267,10 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
   ALVQ_REQUIRE((long)B * (L + 1) < (1L << 30), ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16: problem too large");
   ConvBArgs a{(const u16*)x, (const u16*)wp, bias, (const u16*)skip1, (const u16*)skip2, (const u16*)mask, (const u16*)post,
               (u16*)y, (u16*)y2, y_ncl, B, L, pad_to(C, TB_K), M, pad_to(M, TB_K), pad_to(M, WP_ROWS), relu,
-              (int)(alvq_nlc_rows(B, L) / TB_R), pad_to(M, TB_M) / TB_M};
+              (int)(alvq_nlc_rows(B, L) / TB_R), pad_to(M, TB_M) / TB_M, (const unsigned char*)mask_bits,
+              (unsigned char*)relu_bits_out};
+  ALVQ_REQUIRE(!(mask && mask_bits), ALVQ_EINVAL, "alvq_conv1d_bf16: pass the mask as a tensor or as bits, not both");
+  ALVQ_REQUIRE(!y_ncl || (!mask_bits && !relu_bits_out), ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16: sign bits go with the NLC output");
   hipStream_t s = (hipStream_t)stream;
   a.relu = relu ? 1 : 0;
   // Wide layers: 256 x 256 tiles whenever the 256-wide m-tile is (nearly) full -- the width-3 kernel with the shared

@@ -64,7 +64,7 @@ _SIGNATURES = {
     "alvq_ncl_to_nlc_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_nlc_to_ncl_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_relu_mask_bf16": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
-    "alvq_conv1d_bf16": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p]),
+    "alvq_conv1d_bf16": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p] * 3),
     "alvq_conv1d_wgrad_bf16_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_bf16": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
     "alvq_conv1d_wgrad_bf16_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p]),
@@ -432,29 +432,39 @@ def spec_rir_wiener(speech_spec, echoed_spec):
 # ----------------------------------------------------------------------------------------------- bf16 path
 class NLC:
     """A bf16 activation in the NLC-padded layout (see include/alvq.h): storage = guard rows + matrix + guard rows."""
-    __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard", "planes")
+    __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard", "planes", "has_bits")
 
     def __init__(self, B, L, C, device, planes=1):
-        """planes=2: the split-bf16 form (hi plane, then the lo plane at +alvq_nlc_plane_bytes)."""
+        """planes=2: the split-bf16 form (hi plane, then the lo plane at +alvq_nlc_plane_bytes).
+        planes=1 buffers carry a tail of rows*Cp/8 bytes for the sign bits a ReLU'd convolution can leave behind
+        (see alvq_conv1d_bf16); ``has_bits`` says whether they are valid."""
         L_ = lib()
         self.B, self.L, self.C, self.planes = B, L, C, planes
         self.Cp = L_.alvq_nlc_channels(C)
         self.rows = L_.alvq_nlc_rows(B, L)
         self.guard = L_.alvq_nlc_guard_rows()
-        self.storage = torch.empty((planes * (self.rows + 2 * self.guard) * self.Cp,), device=device, dtype=torch.bfloat16)
+        self.has_bits = False
+        n = planes * (self.rows + 2 * self.guard) * self.Cp + (self.rows * self.Cp // 16 if planes == 1 else 0)
+        self.storage = torch.empty((n,), device=device, dtype=torch.bfloat16)
 
     @classmethod
-    def wrap(cls, storage, B, L, C, planes=1):
+    def wrap(cls, storage, B, L, C, planes=1, has_bits=False):
         self = cls.__new__(cls)
         L_ = lib()
         self.B, self.L, self.C, self.planes = B, L, C, planes
         self.Cp, self.rows, self.guard = L_.alvq_nlc_channels(C), L_.alvq_nlc_rows(B, L), L_.alvq_nlc_guard_rows()
         self.storage = storage
+        self.has_bits = bool(has_bits) and storage.numel() >= (self.rows + 2 * self.guard) * self.Cp + self.rows * self.Cp // 16
         return self
 
     @property
     def ptr(self):
         return self.storage.data_ptr() + self.guard * self.Cp * 2
+
+    @property
+    def bits_ptr(self):
+        """Sign-bit area behind the matrix (planes == 1 only)."""
+        return self.storage.data_ptr() + (self.rows + 2 * self.guard) * self.Cp * 2
 
     def matrix(self, plane=0):
         g = (self.guard + plane * (self.rows + 2 * self.guard)) * self.Cp
@@ -562,6 +572,9 @@ def relu_mask_bf16(dy, t):
     return out
 
 
+USE_SIGN_BITS = os.environ.get("ALVQ_SIGN_BITS", "1") != "0"
+
+
 def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, out_ncl=False):
     """x: NLC; packed = pack_weight(...).  Returns NLC y, (y, y2) with post, or a (B,M,L) fp32 tensor if out_ncl."""
     wp, (M, C, KW, wplanes) = packed
@@ -587,12 +600,23 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
         wide = ((M + 255) // 256 * 256 - M) <= 32 and (x.rows // 256) * ((M + 255) // 256) >= min_tiles
         family = ("conv1d_bf16_k3_kernel" if KW == 3 else "conv1d_bf16_v2_kernel") if wide else "conv1d_bf16_kernel"
         fn = lib().alvq_conv1d_bf16
+    # sign bits: a ReLU'd bf16 output records them; a mask operand that carries valid bits is passed as bits
+    extra = ()
+    mask_ptr = _nlc_ptr(mask, x, M, "mask")
+    if not split:
+        mask_bits = None
+        if mask is not None and mask.has_bits and USE_SIGN_BITS:
+            mask_bits, mask_ptr = mask.bits_ptr, None
+        bits_out = y.bits_ptr if (y is not None and relu and USE_SIGN_BITS) else None
+        extra = (mask_bits, bits_out)
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
         rc = fn(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),
-                                    _nlc_ptr(skip2, x, M, "skip2"), _nlc_ptr(mask, x, M, "mask"),
+                                    _nlc_ptr(skip2, x, M, "skip2"), mask_ptr,
                                     _nlc_ptr(post, x, M, "post"), y.ptr if y is not None else None,
                                     y2.ptr if y2 is not None else None, _ptr(y_ncl), x.B, C, M, x.L, KW,
-                                    int(bool(relu)), _stream())
+                                    int(bool(relu)), *extra, _stream())
+    if not split and y is not None and relu and USE_SIGN_BITS:
+        y.has_bits = True
     _check(rc, "alvq_conv1d_bf16")
     if out_ncl:
         return y_ncl

@@ -240,7 +240,7 @@ class _BF16Engine:
         return N.conv1d_wgrad_bf16_multi if self.planes == 1 else None
 
     def pack(self, act):
-        return act.storage, (act.B, act.L, act.C, act.planes)
+        return act.storage, (act.B, act.L, act.C, act.planes, act.has_bits)
 
     def unpack(self, tensor, meta):
         return N.NLC.wrap(tensor, *meta)

@@ -222,10 +222,15 @@ int alvq_nlc_to_ncl_f32(const void* x, float* y, int B, int C, int L, void* stre
 int alvq_relu_mask_bf16(const void* dy, const void* t, void* out, int64_t n, void* stream);
 
 /* Same fused convolution as alvq_conv1d_f32 on NLC-padded bf16 operands and a packed weight.  Exactly one of
- * y (NLC bf16, row stride alvq_nlc_channels(M)) and y_ncl ((B,M,L) fp32, bias-only epilogue) is non-NULL. */
+ * y (NLC bf16, row stride alvq_nlc_channels(M)) and y_ncl ((B,M,L) fp32, bias-only epilogue) is non-NULL.
+ * Sign bits (both optional, NLC output only): a byte per 8 consecutive channels of a row,
+ * bits[row * alvq_nlc_channels(M) / 8 + m / 8], bit (m % 8) = (value > 0); alvq_nlc_rows(B,L) * alvq_nlc_channels(M) / 8
+ * bytes.  relu_bits_out receives the signs of the stored y, so that the data-gradient launch that later needs
+ * "* (y > 0)" can pass them as mask_bits (instead of `mask` = the tensor itself) and read 1/16 of the bytes. */
 int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
                      const void* mask, const void* post, void* y, void* y2, float* y_ncl,
-                     int B, int C, int M, int L, int KW, int relu, void* stream);
+                     int B, int C, int M, int L, int KW, int relu, const void* mask_bits, void* relu_bits_out,
+                     void* stream);
 
 /* Weight (and bias) gradient from NLC-padded bf16 dy [rows][Mp] and x [rows][Cp]; fp32 result in the weight's
  * native layout, same contract as alvq_conv1d_wgrad_f32. */

@@ -164,3 +164,27 @@ def test_pack_weights_batch_matches_single_packs(planes):
     for (w, img, layout), (ref, tag) in zip(entries, singles):
         assert tag[3] == planes
         assert torch.equal(img.view(torch.int16), ref.view(torch.int16)), (tuple(w.shape), layout)
+
+
+@pytest.mark.parametrize("M,KW", [(1024, 3), (1000, 1), (72, 3)])
+def test_relu_sign_bits_replace_the_mask_tensor(M, KW):
+    """A ReLU'd output leaves its sign bits behind (one byte per 8 channels of a row); the masked launch that later needs
+    "* (y > 0)" gives bit-identical results whether it reads those bits or the tensor itself -- wide and narrow kernels."""
+    torch.manual_seed(31)
+    B, C, L = 3, 72, 140
+    x = torch.randn(B, C, L)
+    w = torch.randn(M, C, KW) / (C * KW) ** 0.5
+    t = N.conv1d_bf16(N.ncl_to_nlc(x.cuda()), N.pack_weight(w.cuda(), N.W_OIK), relu=True)
+    assert t.has_bits
+    # the bits are the signs of the stored tensor, padding and gap rows included
+    bits = t.storage.view(torch.uint8)[(t.rows + 2 * t.guard) * t.Cp * 2:][:t.rows * t.Cp // 8].view(t.rows, t.Cp // 8)
+    want = (t.matrix().float() > 0).view(t.rows, t.Cp // 8, 8).to(torch.int32)
+    want = (want << torch.arange(8, device="cuda", dtype=torch.int32)).sum(dim=2).to(torch.uint8)
+    assert torch.equal(bits, want)
+    dy = N.ncl_to_nlc(torch.randn(B, M, L).cuda())
+    wd = torch.randn(M, M, 1).cuda() / M ** 0.5
+    pk = N.pack_weight(wd, N.W_OIK)
+    got_bits = N.conv1d_bf16(dy, pk, mask=t)                       # t.has_bits -> passed as bits
+    t_plain = N.NLC.wrap(t.storage, t.B, t.L, t.C, 1, has_bits=False)
+    got_tensor = N.conv1d_bf16(dy, pk, mask=t_plain)
+    assert torch.equal(got_bits.matrix(), got_tensor.matrix())
