@@ -27,6 +27,19 @@ inline int check_launch(const char* what) {
     }                                  \
   } while (0)
 
+// hipFuncSetAttribute applies to the current device only: a launch site remembers which devices it has configured
+// (a process may drive more than one card; the kernels that ask for more than 64 KB of LDS fail to launch otherwise)
+struct DeviceOnce {
+  bool done[64] = {};
+  bool need() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 constexpr int kWave = 64;  // CDNA wavefront
 constexpr int kNumXcd = 8;
 

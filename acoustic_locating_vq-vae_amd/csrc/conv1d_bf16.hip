@@ -287,13 +287,12 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
   if (min_tiles < 0) min_tiles = getenv("ALVQ_WIDE_MIN_TILES") ? atol(getenv("ALVQ_WIDE_MIN_TILES")) : ALVQ_WIDE_MIN_TILES;
   if (use_v2 && pad_to(M, 256) - M <= 32 && tiles256 >= min_tiles)
     return (KW == 3 && use_k3) ? conv1d_bf16_k3_launch(a, s) : conv1d_bf16_v2_launch(a, KW, s);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr = true;
   }
   const dim3 grid(a.rtiles * a.mtiles), block(256);
   if (KW == 3) {

@@ -161,11 +161,10 @@ int conv1d_bf16_v2_launch(const ConvBArgs& a_in, int KW, hipStream_t stream) {
   const long rows = (long)a.rtiles * TB_R;     // caller computed rtiles in 128-row units; rows % 256 == 0
   a.rtiles = (int)(rows / V2_R);
   a.mtiles = (a.M + V2_M - 1) / V2_M;
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_v2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
-    attr = true;
   }
   const dim3 grid(a.rtiles * a.mtiles), block(512);
   if (a.y) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0>), grid, block, V2_LDS, stream, a, KW);

@@ -108,8 +108,169 @@ __device__ __forceinline__ void wave_epilogue_x3(const ConvX3Args& ax, const f32
   }
 }
 
+// Main kernel.  A K-tile = (32 channels, one tap) = four 16 KB slabs (W hi, W lo, X hi, X lo) in one of two LDS stages;
+// per wave it is three phases of 32 MFMAs on the same 8 x 4 accumulators:
+//   phase 1  hi*hi : A0 = W hi fragments, BX = X hi        | meanwhile: read X lo -> BY, first half of W lo -> A1
+//   phase 2  hi*lo : A0, BY                                 | meanwhile: second half of W lo -> A1
+//            s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      <- K-tile t+1 has landed; every read of this stage is done
+//   phase 3  lo*hi : A1, BX                                 | meanwhile: DMA of K-tile t+2 into THIS stage; the hi
+//                                                             fragments of K-tile t+1 -> A0 (dead since phase 2) and BY
+// so the barrier falls between phases whose operands are already in registers: no fragment read is ever exposed
+// behind it, every LDS read has at least half a phase (16 MFMAs) to return, every DMA piece has three phases to land
+// and the X fragment sets swap roles from one K-tile to the next (BX <-> BY).  96 fragment VGPRs + 128 accumulators.
+// MFMAs are tied inline asm (hipcc does not tie the builtin's destination to its C operand and then shuffles the
+// accumulators through spare registers it does not have here); DMA pieces are inline asm with a scalar base and one
+// 32-bit lane offset, as in conv1d_bf16_k3.hip.
 template <int OUT>
 __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, int KW) {
+  const ConvBArgs& a = ax.b;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int PAD = (KW - 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
+  const int m0 = (tile % a.mtiles) * X3_M;
+  const int r0 = (tile / a.mtiles) * X3_R;
+  const int Cp = a.Cp;
+
+  // ---- DMA: a piece is 16 rows x 64 B; lane i -> row i>>2, slot i&3 <- channel group (i&3) ^ h[(row>>2)&3]
+  const int hsel = (lane >> 4) & 3;
+  const int hval = (hsel == 0) ? 0 : (4 - hsel);
+  const int srow = lane >> 2, sgrp = (lane & 3) ^ hval;
+  const unsigned lane_off = (unsigned)(srow * Cp + sgrp * 8) * 2u;
+  const long tap_w = (long)a.Mp128 * Cp * 2;                   // bytes per tap of packed weights
+  const long row16 = (long)Cp * 32;                            // bytes per 16 rows
+  const long wpl = ax.wp_plane * 2, xpl = ax.x_plane * 2;      // hi -> lo plane, bytes
+  const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) unsigned char*)lds);
+  auto dma = [&](const char* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+  };
+  const char* const wb = (const char*)(a.wp + ((long)m0 + wave * 32) * Cp);
+  const char* const xb = (const char*)(a.x + ((long)r0 - PAD + wave * 32) * Cp);
+  int is_chunk = 0, is_tap = 0;   // K-tile the next issue() stages
+  auto issue = [&](int stage) {   // 8 pieces per wave: 32 rows of each slab
+    const unsigned dst = lds0 + stage * X3_STAGE + wave * 2048;
+    const char* ws = wb + is_tap * tap_w + is_chunk * (X3_K * 2);
+    const char* xs = xb + (long)is_tap * Cp * 2 + is_chunk * (X3_K * 2);
+    dma(ws, dst);
+    dma(ws + row16, dst + 1024);
+    dma(ws + wpl, dst + X3_SLAB);
+    dma(ws + wpl + row16, dst + X3_SLAB + 1024);
+    dma(xs, dst + 2 * X3_SLAB);
+    dma(xs + row16, dst + 2 * X3_SLAB + 1024);
+    dma(xs + xpl, dst + 3 * X3_SLAB);
+    dma(xs + xpl + row16, dst + 3 * X3_SLAB + 1024);
+    if (++is_tap == KW) {
+      is_tap = 0;
+      ++is_chunk;
+    }
+  };
+
+  // ---- fragment reads (same lane offset for both operands; plane 0 = hi, 1 = lo)
+  const int loff = li * 64 + ((kq ^ ((((li >> 2) & 3) == 0) ? 0 : (4 - ((li >> 2) & 3)))) << 4);
+  const unsigned char* const abase = lds + wm0 * 64 + loff;
+  const unsigned char* const bbase = lds + 2 * X3_SLAB + wn0 * 64 + loff;
+  bf16x8_t fa0[8], fa1[8], fb0[4], fb1[4];
+#define X3_RDA(DST, HALF, STAGE, PLANE)                                                            \
+  {                                                                                                \
+    const unsigned char* pa_ = abase + (STAGE) * X3_STAGE + (PLANE) * X3_SLAB;                     \
+    _Pragma("unroll") for (int mi = (HALF) * 4; mi < (HALF) * 4 + 4; ++mi) DST[mi] = *(const bf16x8_t*)(pa_ + mi * 1024); \
+  }
+#define X3_RDB(DST, STAGE, PLANE)                                                                  \
+  {                                                                                                \
+    const unsigned char* pb_ = bbase + (STAGE) * X3_STAGE + (PLANE) * X3_SLAB;                     \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) DST[ni] = *(const bf16x8_t*)(pb_ + ni * 1024); \
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define X3_MM(A, B, HALF)                                                                          \
+  _Pragma("unroll") for (int mi = (HALF) * 4; mi < (HALF) * 4 + 4; ++mi)                           \
+  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                 \
+      asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(A[mi]), "v"(B[ni]));
+#define X3_SB __builtin_amdgcn_sched_barrier(0);
+
+  const int n = (Cp / X3_K) * KW;   // K-tiles; even (Cp % 64 == 0)
+  const bool early = wave < 4;      // the two waves of a SIMD issue their DMA at different points of phase 3
+
+  // ---- prologue: K-tile 0 landed, K-tile 1 in flight, hi fragments of K-tile 0 in A0 / fb0
+  issue(0);
+  issue(1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  X3_RDA(fa0, 0, 0, 0)
+  X3_RDA(fa0, 1, 0, 0)
+  X3_RDB(fb0, 0, 0)
+
+  // one K-tile in stage S with X hi in BX; BY receives X lo and, in phase 3, the next K-tile's X hi
+#define X3_TILE(S, BX, BY, MORE)                                                                   \
+  X3_MM(fa0, BX, 0) X3_SB X3_RDB(BY, S, 1) X3_SB                                                   \
+  X3_MM(fa0, BX, 1) X3_SB X3_RDA(fa1, 0, S, 1) X3_SB                                               \
+  X3_MM(fa0, BY, 0) X3_SB X3_RDA(fa1, 1, S, 1) X3_SB                                               \
+  X3_MM(fa0, BY, 1) X3_SB                                                                          \
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+  __builtin_amdgcn_s_barrier();                                                                    \
+  if (early && (MORE)) issue(S);                                                                   \
+  X3_MM(fa1, BX, 0) X3_SB X3_RDA(fa0, 0, (S) ^ 1, 0) X3_RDB(BY, (S) ^ 1, 0) X3_SB                  \
+  if (!early && (MORE)) issue(S);                                                                  \
+  X3_MM(fa1, BX, 1) X3_SB X3_RDA(fa0, 1, (S) ^ 1, 0) X3_SB
+
+  for (int t = 0; t < n; t += 2) {
+    X3_TILE(0, fb0, fb1, t + 2 < n)
+    X3_TILE(1, fb1, fb0, t + 3 < n)
+  }
+#undef X3_TILE
+#undef X3_SB
+#undef X3_MM
+#undef X3_RDB
+#undef X3_RDA
+  // the compiler's hazard recogniser does not see inside the asm MFMAs: cover the MFMA-result -> VALU-read wait
+  // states by hand before the epilogue touches the accumulators
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+  if (OUT == 0) {   // bf16 hi + lo planes, straight from the accumulators
+    wave_epilogue_x3(ax, acc, m0, r0, li, kq, wm0, wn0);
+    return;
+  }
+  __syncthreads();   // the C slab overlays the stages: the trailing fragment reads of every wave must be done
+  // ---- OUT == 1 (fp32 NCL, bias only): four 64-row slabs through an fp32 LDS tile
+  float* Cs = (float*)lds;
+  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  for (int slab = 0; slab < 4; ++slab) {
+    if ((wave & 3) == slab) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int rl = ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
+          *(f32x4*)(Cs + rl * X3_CS + ml) = acc[mi][ni];
+        }
+    }
+    __syncthreads();
+    {
+      const int rl = tid & 63, row = r0 + slab * 64 + rl;
+      int b, l;
+      if (row_valid(row, Lp1, ndata, &b, &l)) {
+        for (int ml = tid >> 6; ml < X3_M; ml += 8) {
+          const int m = m0 + ml;
+          if (m >= a.M) break;
+          a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * X3_CS + ml] + (a.bias ? a.bias[m] : 0.f);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int OUT>
+__global__ __launch_bounds__(512, 2) void conv1d_bf16x3_old_kernel(ConvX3Args ax, int KW) {
   const ConvBArgs& a = ax.b;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int PAD = (KW - 1) / 2;
@@ -584,13 +745,20 @@ extern "C" int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bi
                 (int)(rows / X3_R), pad_to(M, X3_M) / X3_M},
                nlc_plane_elems(B, L, C), (long)alvq_packed_weight_elems(M, C, KW), nlc_plane_elems(B, L, M)};
   hipStream_t s = (hipStream_t)stream;
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
-    attr = true;
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_old_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_old_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
   }
+  static const bool use_old = getenv("ALVQ_X3_OLD") && atoi(getenv("ALVQ_X3_OLD")) != 0;    // A/B switch (temporary)
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
+  if (use_old) {
+    if (y) hipLaunchKernelGGL((conv1d_bf16x3_old_kernel<0>), grid, block, X3_LDS, s, a, KW);
+    else hipLaunchKernelGGL((conv1d_bf16x3_old_kernel<1>), grid, block, X3_LDS, s, a, KW);
+    return check_launch("alvq_conv1d_bf16x3");
+  }
   if (y) hipLaunchKernelGGL((conv1d_bf16x3_kernel<0>), grid, block, X3_LDS, s, a, KW);
   else hipLaunchKernelGGL((conv1d_bf16x3_kernel<1>), grid, block, X3_LDS, s, a, KW);
   return check_launch("alvq_conv1d_bf16x3");
@@ -617,11 +785,10 @@ extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw
   WgradX3Args a{(const u16*)dy, (const u16*)x, (float*)workspace, nlc_plane_elems(B, L, M), nlc_plane_elems(B, L, C),
                 pad_to(M, 64), pad_to(C, 64), M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, rows};
   a.splits = wgrad_x3_splits(rows, a.mtiles * a.ctiles, &a.chunks_per_split);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16x3_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_x3_lds<3, 2>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16x3_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_x3_lds<1, 4>());
-    attr = true;
   }
   const int grid = a.mtiles * a.ctiles * a.splits;
   if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_bf16x3_kernel<3, 2>), dim3(grid), dim3(512), (wgrad_x3_lds<3, 2>()), s, a);

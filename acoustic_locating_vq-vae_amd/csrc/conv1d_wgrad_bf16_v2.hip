@@ -336,11 +336,10 @@ int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int
   a.mtiles = (M + 127) / 128; a.ctiles = (C + ct - 1) / ct;
   a.total_rows = total_rows; a.nseg = nseg;
   a.splits = wgrad_v2_splits(nseg * total_rows, a.mtiles * a.ctiles, &a.chunks_per_split);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<3, 2>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<1, 4>());
-    attr = true;
   }
   const int grid = a.mtiles * a.ctiles * a.splits;
   if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<3, 2>), dim3(grid), dim3(512), (wgrad_v2_lds<3, 2>()), s, a);

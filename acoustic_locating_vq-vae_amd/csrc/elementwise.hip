@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* dy, const f
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) out[e] = t[e] > 0.f ? dy[e] : 0.f;
 }
 
+__global__ __launch_bounds__(256) void fill_kernel(float* out, float v, long n) {
+  const f32x4 v4 = {v, v, v, v};
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) ((f32x4*)out)[i] = v4;
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = v;
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* out, long n) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) out[e] = a[e] + b[e];
 }
@@ -256,6 +263,14 @@ extern "C" int alvq_mse_backward_f32(const float* a, const float* b, const float
   hipLaunchKernelGGL(mse_backward_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, grad_loss, grad,
                      (long)n, (float)(2.0 / (double)n));
   return check_launch("alvq_mse_backward_f32");
+}
+
+extern "C" int alvq_fill_f32(float* out, float value, int64_t n, void* stream) {
+  ALVQ_REQUIRE(out, ALVQ_EINVAL, "alvq_fill_f32: null pointer");
+  ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_fill_f32: n <= 0");
+  ALVQ_REQUIRE(((uintptr_t)out & 15) == 0, ALVQ_EINVAL, "alvq_fill_f32: out must be 16-byte aligned");
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, value, (long)n);
+  return check_launch("alvq_fill_f32");
 }
 
 extern "C" int alvq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {

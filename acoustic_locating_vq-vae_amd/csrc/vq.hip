@@ -387,11 +387,10 @@ extern "C" int alvq_vq_argmin_f32(const float* x, const float* codebook, int64_t
   const int Dp = (D + VQ_DK - 1) / VQ_DK * VQ_DK;
   const int XSTR = vq_pad32(Dp, 2);
   ArgminArgs a{x, codebook, xn, en, idx, min_dist, (long)N, K, D, Dp, XSTR};
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   // 8 waves (128 rows) from D = 128 up: a 4-wave workgroup would leave one wave per SIMD there, and 128-row blocks
   // halve the codebook-tile traffic per row (+7 % at the speech size)

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "alvq_standardise_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_mse_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p]),
     "alvq_mse_backward_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p]),
+    "alvq_fill_f32": (_i32, [_c_void_p, _f32, _i64, _c_void_p]),
     "alvq_add_f32": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
     "alvq_relu_mask_f32": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
     "alvq_transpose_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
@@ -202,13 +203,22 @@ def conv1d(x, w, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=F
 
 
 _WS = {}
+_WS_RETIRED = []
 
 
 def _workspace(nbytes, device):
-    """Grow-only scratch per device (caller-owned from the library's point of view)."""
-    key = (device.type, device.index)
+    """Grow-only scratch per (device, stream), caller-owned from the library's point of view.
+
+    A buffer that has been handed out is never released: a captured hipGraph records the raw pointer of the
+    scratch its launches used (weight-gradient split partials, VQ norms, codebook-gradient partials), so when a
+    later, larger request outgrows the buffer the old one is parked in ``_WS_RETIRED`` instead of going back to
+    the caching allocator, where a replay would scribble over whoever owns the memory next.  Keyed by stream as
+    well: launches on different streams are not ordered against each other and must not share scratch."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _WS_RETIRED.append(buf)
         buf = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
         _WS[key] = buf
     return buf
@@ -325,6 +335,13 @@ def mse_backward(a, b, grad_loss):
     _check(lib().alvq_mse_backward_f32(_ptr(a, name="a"), _ptr(b, name="b"), _ptr(grad_loss, name="grad_loss"), _ptr(grad),
                                        a.numel(), _stream()), "alvq_mse_backward_f32")
     return grad
+
+
+def fill_(t, value=0.0):
+    """t[...] = value in place (fp32, contiguous, 16-byte aligned start)."""
+    if t.numel():
+        _check(lib().alvq_fill_f32(_ptr(t, name="t"), float(value), t.numel(), _stream()), "alvq_fill_f32")
+    return t
 
 
 def add(a, b):

@@ -60,8 +60,28 @@ def register_grad_sinks(params):
             _GRAD_SINKS[p.data_ptr()] = p.grad
 
 
+_SINKS_ACTIVE = 0
+
+
+class use_grad_sinks:
+    """Scope of the gradient sinks: only inside ``with use_grad_sinks():`` (the body of a Trainer step) do the
+    weight-gradient launches write into the flat buffer and the autograd nodes return None for those weights.
+    Everywhere else -- ``torch.autograd.grad`` on the same model, a plain ``loss.backward()`` from user code --
+    autograd sees ordinary gradient tensors."""
+
+    def __enter__(self):
+        global _SINKS_ACTIVE
+        _SINKS_ACTIVE += 1
+
+    def __exit__(self, *exc):
+        global _SINKS_ACTIVE
+        _SINKS_ACTIVE -= 1
+
+
 def _sink(t):
-    return _GRAD_SINKS.get(t.data_ptr()) if (t is not None and len(_GRAD_SINKS)) else None
+    if t is None or not _SINKS_ACTIVE or not len(_GRAD_SINKS) or not t.requires_grad:
+        return None
+    return _GRAD_SINKS.get(t.data_ptr())
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -143,7 +163,14 @@ class use_pack_pool:
 
 def _wgrad(eng, dy, x, kw, layout, w, b=None, dw_prev=None):
     """(dw, db) of one conv use.  Sinked tensors come back as None (already accumulated in place); otherwise dw is
-    accumulated onto ``dw_prev`` (shared residual weights) or freshly allocated."""
+    accumulated onto ``dw_prev`` (shared residual weights) or freshly allocated.  A frozen weight
+    (``requires_grad_(False)``) costs nothing: no launch, no sink write, gradient None -- as autograd would."""
+    if b is not None and not b.requires_grad:
+        b = None
+    if not w.requires_grad:
+        if b is None:
+            return None, None
+        raise RuntimeError("a convolution with a frozen weight and a trainable bias is not supported on the HIP path")
     sw, sb = _sink(w), _sink(b)
     if sw is not None and (b is None or sb is not None):
         eng.wgrad(dy, x, kw, layout, want_bias=b is not None, dw_out=sw, dbias_out=sb, accumulate=True)
@@ -297,14 +324,17 @@ def _stack_backward(eng, dh, ts, us, w1, w2, R, outer=None):
     """dh = grad wrt h_R, already masked by (t_{R+1} > 0).  outer = extra grad flowing into t_1 (encoder skip).
     Returns (dh0 masked by t_1>0, dW1, dW2) with the R uses of the shared weights summed in a fixed order."""
     dw1 = dw2 = None
-    fused = getattr(eng, "wgrad_multi", None) is not None and 1 < R <= 4
+    if w1.requires_grad != w2.requires_grad:
+        raise RuntimeError("the two weights of the shared Residual must be frozen or trainable together")
+    train = w1.requires_grad
+    fused = train and getattr(eng, "wgrad_multi", None) is not None and 1 < R <= 4
     pairs1, pairs2 = [], []
     for r in range(R - 1, -1, -1):
         du = eng.conv(dh, w2, IOK, mask=us[r])                                 # k1 data-grad, * (u_r > 0)
         if fused:                                                              # one launch per shared weight, below
             pairs2.append((dh, us[r]))
             pairs1.append((du, ts[r]))
-        else:
+        elif train:
             dw2, _ = _wgrad(eng, dh, us[r], 1, OIK, w2, dw_prev=dw2)
             dw1, _ = _wgrad(eng, du, ts[r], 3, OIK, w1, dw_prev=dw1)
         dh = eng.conv(du, w1, IOK, skip1=dh, skip2=outer if r == 0 else None, mask=ts[r])
@@ -316,7 +346,15 @@ def _stack_backward(eng, dh, ts, us, w1, w2, R, outer=None):
     return dh, dw1, dw2
 
 
+def _check_layers(R):
+    if R < 1:
+        # with no residual layer the reference's in-place ReLU never runs, so its encoder returns relu(h0) + h0
+        # (convolutional_encoder.py:42) -- a different function from the R >= 1 chain built here
+        raise NotImplementedError("num_residual_layers=0 is not supported on the HIP path (no script uses it)")
+
+
 def _encoder_forward(eng, x, wc, bc, w1, w2, R):
+    _check_layers(R)
     xi = eng.enter(x)
     t1 = eng.conv(xi, wc, bias=bc, relu=True)
     ts, us, out = _stack_forward(eng, t1, w1, w2, R, post=t1)
@@ -383,6 +421,7 @@ class StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h0, w1, w2, R):
         eng = _engine()
+        _check_layers(R)
         hi = eng.enter(h0)
         t1 = eng.relu_mask(hi, hi)
         ts, us, out = _stack_forward(eng, t1, w1, w2, R)
@@ -466,6 +505,7 @@ class DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, src, wd, bd, w1, w2, wt1, bt1, wt2, bt2, wt3, bt3, R):
         eng = _engine()
+        _check_layers(R)
         q = dense(q)
         qj = eng.enter(N.jitter_gather(q, src) if src is not None else q)
         t1 = eng.conv(qj, wd, bias=bd, relu=True)
@@ -560,9 +600,9 @@ def jitter_source_index(length, probability):
     many are drawn (identical values, identical final generator state)."""
     rng = np.random.mtrand._rand          # the global RandomState that np.random.choice uses
     p = float(probability)
-    if length < 2:                        # no neighbour to copy from (the reference would raise IndexError)
-        rng.random_sample(length)
-        return np.arange(length, dtype=np.int32)
+    if length < 2:                        # no neighbour to copy from: jitter.py:57-60 indexes column 1 / -1 of a
+        # one-column tensor (e.g. encoder_average_pooling=True in training mode) and raises
+        raise IndexError("index 1 is out of bounds for dimension 2 with size %d (Jitter needs at least 2 columns)" % length)
     cdf0 = np.cumsum(np.array([p, 1.0 - p]))
     cdf0 /= cdf0[-1]
     thr = float(cdf0[0])                  # same normalisation as choice()

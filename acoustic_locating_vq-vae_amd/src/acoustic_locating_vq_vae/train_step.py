@@ -7,10 +7,11 @@ reproduces one step of each loop on the HIP path and adds what the north star as
 * ``FlatBuffers``   -- every trainable parameter (and its ``.grad``) is a view into one flat fp32 buffer;
 * ``sync_grads`` / ``sync_span`` -- the step's all-reduce(sum) of the flat gradient buffer (RCCL over xGMI when
                        the process group backend is "nccl"; "gloo" on CPU for tests); the 1/world factor is folded
-                       into the optimiser kernel.  The buffer is reduced exactly once per step.  By default the
-                       VQ-VAE trainers issue that reduction as two contiguous spans -- quantiser + decoder gradients
-                       as soon as they exist, encoder gradients at the end -- so the first overlaps the encoder's
-                       backward (``ALVQ_GRAD_BUCKETS=1`` / ``Trainer(grad_buckets=1)``: one call after the backward);
+                       into the optimiser kernel.  The buffer is reduced exactly once per step: by default as ONE
+                       all-reduce after the backward (what BASELINE.json's north_star specifies).  Optionally
+                       (``ALVQ_GRAD_BUCKETS=2`` / ``Trainer(grad_buckets=2)``) as two contiguous spans -- quantiser +
+                       decoder gradients as soon as they exist, encoder gradients at the end -- so the first overlaps
+                       the encoder's backward; ``bench.py --gpus N`` times both and reports them side by side;
 * ``FlatAdam``      -- torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, amsgrad=False) arithmetic
                        (train_speech.py:154) as one HIP launch over the flat buffer.
 
@@ -64,7 +65,10 @@ class FlatBuffers:
 
     def zero_grad(self):
         """Keeps the views alive (optimizer.zero_grad(set_to_none=True) would drop them)."""
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            N.fill_(self.grad, 0.0)                  # the library's own fill: no ATen compute op on the step path
+        else:
+            self.grad.zero_()                        # CPU buffers exist only in the gloo plumbing tests
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)
@@ -127,9 +131,16 @@ class FlatAdam:
         self.step_count += 1
         N.adam_advance(self.scalars, self.lr, self.betas[0], self.betas[1], grad_scale)
 
-    def apply(self):
-        N.adam_step_dev(self.b.flat, self.b.grad, self.exp_avg, self.exp_avg_sq, self.scalars, self.betas[0],
-                        self.betas[1], self.eps)
+    def apply(self, skip=()):
+        """One Adam launch over the flat buffer; ``skip`` = [lo, hi) element ranges that received no gradient this
+        step (torch.optim.Adam leaves a parameter whose ``.grad`` is None untouched, moments included -- e.g. the
+        codebook under ``set_train_vq(False)``): the launch is then split around them."""
+        lo = 0
+        for s_lo, s_hi in sorted(skip) + [(self.b.flat.numel(), self.b.flat.numel())]:
+            if s_lo > lo:
+                N.adam_step_dev(self.b.flat[lo:s_lo], self.b.grad[lo:s_lo], self.exp_avg[lo:s_lo],
+                                self.exp_avg_sq[lo:s_lo], self.scalars, self.betas[0], self.betas[1], self.eps)
+            lo = max(lo, s_hi)
 
     def step(self, grad_scale=1.0):
         self.prepare(grad_scale)
@@ -155,12 +166,14 @@ class Trainer:
 
     def __init__(self, model, kind="speech", lr=1e-3, group=None, grad_buckets=None):
         self.model, self.kind, self.group = model, kind, group
-        params = model._decoder.parameters() if kind == "echoed" else model.parameters()
-        if kind == "echoed":
-            for m in (model.rir_model, model.speech_model):
-                for p in m.parameters():
-                    p.requires_grad_(False)   # only the decoder ever receives gradients (echoed_speech_model.py:53-54)
+        # echoed loop: the reference hands Adam every parameter (train_echoed_speech.py:48) but detaches both encoder
+        # outputs unless set_train_encoder(True) was called (echoed_speech_model.py:51-54), so only the decoder's
+        # tensors ever receive gradients -- the flat buffers (and the all-reduce) hold exactly the tensors that do.
+        # The caller's sub-models are left as they are (no requires_grad mutation).
+        self._echoed_train_encoder = bool(getattr(model, "flag_train_encoder", False)) if kind == "echoed" else None
+        params = model._decoder.parameters() if (kind == "echoed" and not self._echoed_train_encoder) else model.parameters()
         self.buffers = FlatBuffers(params)
+        self._trainable = [p.requires_grad for p in self.buffers.params]
         if self.buffers.flat.is_cuda:
             _ops.register_grad_sinks(self.buffers.params)     # weight-grad launches accumulate straight into the flat buffer
         # every conv weight of the model (frozen sub-models of the echoed config included) keeps persistent packed
@@ -177,7 +190,7 @@ class Trainer:
         # bucket's all-reduce overlaps the late part's kernels (see ``step``).  The echoed loop trains the decoder
         # only: one part, one bucket.
         self._buckets = None
-        want_buckets = int(os.environ.get("ALVQ_GRAD_BUCKETS", "2")) if grad_buckets is None else grad_buckets
+        want_buckets = int(os.environ.get("ALVQ_GRAD_BUCKETS", "1")) if grad_buckets is None else grad_buckets
         if want_buckets >= 2 and kind != "echoed" and hasattr(model, "_encoder") and hasattr(model, "_pre_vq_conv"):
             late = unique_trainable(list(model._encoder.parameters()) + list(model._pre_vq_conv.parameters()))
             late_ids = {id(p) for p in late}
@@ -208,12 +221,33 @@ class Trainer:
         recon_error = _ops.MSEFn.apply(recon, target)
         return recon_error + vq_loss, recon_error, perplexity
 
+    def _check_frozen(self):
+        """The flat buffers were laid out for the parameters that were trainable at construction; Adam walks the
+        whole buffer, so a later ``requires_grad_(False)`` / ``set_train_encoder`` toggle would silently keep
+        training (or never train) those tensors.  Fail loudly instead."""
+        if [p.requires_grad for p in self.buffers.params] != self._trainable:
+            raise RuntimeError("requires_grad of a parameter changed after the Trainer was built; build a new Trainer")
+        if self.kind == "echoed" and bool(self.model.flag_train_encoder) != self._echoed_train_encoder:
+            raise RuntimeError("set_train_encoder(%s) was called after the Trainer was built; build a new Trainer so "
+                               "the encoders' parameters are (not) part of the optimiser" % self.model.flag_train_encoder)
+
+    def _adam_skip(self):
+        """Ranges of the flat buffer whose parameter gets no gradient this step: the codebook when its quantiser
+        runs with ``set_train_vq(False)`` (vector_quantizer.py:46-50 detaches both MSE terms)."""
+        skip = []
+        ids = {id(p): i for i, p in enumerate(self.buffers.params)}
+        for m in self.model.modules():
+            if hasattr(m, "_train_vq") and not m._train_vq and id(m._embedding.weight) in ids:
+                i = ids[id(m._embedding.weight)]
+                skip.append((self.buffers.offsets[i], self.buffers.offsets[i] + m._embedding.weight.numel()))
+        return skip
+
     def _body(self, raw, wiener):
         """Preprocess + forward + first part of the backward (everything above the encoder output, or the whole
         backward when the model has a single bucket).  ``_body`` and ``_body_late`` are the launch-bound part of a
         step (~130 launches) that hipGraphs capture; the collectives and the optimiser launch stay outside so no
         RCCL call is ever recorded into a graph."""
-        with _ops.use_pack_pool(self.pack_pool):            # one batched re-pack of every conv weight, then lookups
+        with _ops.use_pack_pool(self.pack_pool), _ops.use_grad_sinks():   # one batched re-pack of every conv weight, then lookups
             x, target = self.preprocess(raw, wiener)
             self.buffers.zero_grad()
             if self._buckets is None:
@@ -232,7 +266,7 @@ class Trainer:
             return
         z, leaf = self._cut
         self._cut = None
-        with _ops.use_pack_pool(self.pack_pool, refresh=False):
+        with _ops.use_pack_pool(self.pack_pool, refresh=False), _ops.use_grad_sinks():
             z.backward(leaf.grad)
 
     def _sync_early(self):
@@ -246,7 +280,7 @@ class Trainer:
             for w in (early_work, late_work):
                 if w is not None:
                     w.wait()                                   # stream-level wait: the Adam launch queues behind both
-        self.opt.apply()                                       # one Adam launch over the flat buffer
+        self.opt.apply(self._adam_skip())                      # one Adam launch over the flat buffer
 
     # ------------------------------------------------------------------------------------------- checkpoint / resume
     def state_dict(self):
@@ -275,6 +309,7 @@ class Trainer:
 
         Order on the stream:  part 1 (fwd + decoder/quantiser backward)  ->  all-reduce(early bucket) starts  ->
         part 2 (encoder backward) runs while it is in flight  ->  all-reduce(late bucket)  ->  Adam."""
+        self._check_frozen()
         if self._graph is None:
             self.opt.prepare(self.grad_scale)
             out = self._body(raw, wiener)

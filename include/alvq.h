@@ -130,6 +130,11 @@ int alvq_mse_f32(const float* a, const float* b, float* loss, void* workspace, i
 /* grad = grad_loss[0] * (2/n) * (a - b)   (grad_loss: device scalar, NULL = 1). */
 int alvq_mse_backward_f32(const float* a, const float* b, const float* grad_loss, float* grad, int64_t n, void* stream);
 
+/* out[0..n) = value (out 16-byte aligned): the flat gradient buffer's zeroing at the top of a step
+ * (optimizer.zero_grad(), train_speech.py:88) as a kernel node -- a memset node recorded during stream capture
+ * was observed not to be ordered before the kernel behind it on replay. */
+int alvq_fill_f32(float* out, float value, int64_t n, void* stream);
+
 /* out = a + b (elementwise), used where a gradient has two consumers. */
 int alvq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 

@@ -202,11 +202,16 @@ def test_g3_default_configs_against_reference_golden(golden_dir, tag):
     vq_loss, recon, perp = m(xg)
     err = F.mse_loss(recon, target.cuda())
     (err + vq_loss).backward()
-    if len(bad) == 0:
-        assert rel(vq_loss, g["vq_loss"]) < TIGHT and rel(err, g["recon_error"]) < TIGHT
-        assert rel(sl(recon), g["recon_slice"]) < TOL
-        # gradients: ~1e-5 forward noise flips a few dozen of the ~1e7 ReLU gates, which bounds the deepest
-        # layers' gradients at a few 1e-3 (measured 4e-3 on _encoder._conv_1.weight; the f32 mode, with 100x less
-        # noise, stays under 1e-3)
-        for key, pp in m.named_parameters():
-            assert rel(sl(pp.grad), g["grad_slice:" + key]) < 1e-2, key
+    # Every comparison below always runs.  With all codes equal to the reference's the split arithmetic is held to its
+    # own precision; if the one permitted near-tie flipped, that row's code vector (1 of ~1000) differs, which moves the
+    # losses by ~1e-3 and the reconstruction locally -- the bounds widen to that and the branch taken is printed.
+    flips = len(bad)
+    t_loss, t_recon, t_grad = (TIGHT, TOL, 1e-2) if flips == 0 else (5e-3, 2e-1, 5e-2)
+    print("g3-%s bf16x3: %d flipped code(s) -> bounds loss %.0e recon %.0e grad %.0e" % (tag, flips, t_loss, t_recon, t_grad))
+    assert rel(vq_loss, g["vq_loss"]) < t_loss and rel(err, g["recon_error"]) < t_loss
+    assert rel(sl(recon), g["recon_slice"]) < t_recon
+    # gradients: ~1e-5 forward noise flips a few dozen of the ~1e7 ReLU gates, which bounds the deepest
+    # layers' gradients at a few 1e-3 (measured 5e-3 on _decoder._conv_1.weight; the f32 mode, with 100x less
+    # noise, stays under 1e-3)
+    for key, pp in m.named_parameters():
+        assert rel(sl(pp.grad), g["grad_slice:" + key]) < t_grad, key

@@ -68,13 +68,19 @@ def test_bf16_forward_backward_close_to_fp32_oracle(cfg, shape, kw, permuted):
     _, _, _, idx = m.eval().get_latent_indices(x.cuda())
     agree = float((idx.cpu() == out["idx"]).float().mean())
     assert agree > 0.9, agree
-    if agree == 1.0:                      # downstream comparisons only make sense on the same codes
-        assert l2(recon, out["recon"]) < 3e-2
-        named = dict(m.named_parameters())
-        for k, v in p.items():
-            if k.startswith("_decoder") and v.numel() >= 1024:
-                # small widths: bf16 rounding flips individual ReLU gates, so only the larger tensors average out
-                assert l2(named[k].grad, v.grad) < 1e-1, k
+    # Downstream of the quantiser the comparison must not depend on which codes flipped: feed the ORACLE's quantised
+    # latent to the decoder (same jitter columns) and compare its output and its parameter gradients -- always runs.
+    m.train()
+    m.zero_grad()
+    np.random.seed(3)
+    recon2 = m._decoder(out["q_st"].detach().cuda())
+    F.mse_loss(recon2, target.cuda()).backward()
+    assert l2(recon2, out["recon"]) < 3e-2
+    named = dict(m.named_parameters())
+    for k, v in p.items():
+        if k.startswith("_decoder") and v.numel() >= 1024:
+            # small widths: bf16 rounding flips individual ReLU gates, so only the larger tensors average out
+            assert l2(named[k].grad, v.grad) < 1e-1, k
 
 
 def test_bf16_matches_f32_mode_on_same_weights_and_codes():
