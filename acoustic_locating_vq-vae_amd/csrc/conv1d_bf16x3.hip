@@ -399,6 +399,7 @@ struct WgradX3Args {
   const u16* dy;
   const u16* x;
   float* partial;
+  float* bias_partial;   // [splits][Mp] column sums of dY (the bias gradient), or null
   long dy_plane, x_plane;
   int Mp, Cp, M, C;
   int mtiles, ctiles, splits, chunks_per_split, total_rows;
@@ -442,15 +443,25 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
   const int x_r = (lane * 16) / XRB, x_s = ((lane * 16) % XRB) >> 4;
   auto src_slot = [](int slot, int row) { return (slot & 16) | (((((slot >> 1) & 7) ^ (row & 7)) << 1) | (slot & 1)); };
   const int last_row = a.total_rows - 1;
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds;
+  // LDS-DMA as inline asm (scalar base + 32-bit lane offset): invisible to the compiler, which would otherwise drain
+  // the whole ring (s_waitcnt vmcnt(0)) in front of every fragment read
+  auto dma = [&](const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  };
+  const char* const dy_hi = (const char*)a.dy;
+  const char* const dy_lo = (const char*)(a.dy + a.dy_plane);
+  const char* const x_hi = (const char*)a.x;
+  const char* const x_lo = (const char*)(a.x + a.x_plane);
   int is_row = rbeg;
   auto issue = [&](int stage) {
-    unsigned char* dst = lds + stage * STAGE;
+    const unsigned dst = lds0 + stage * STAGE;
     {
       const int lr = 4 * wave + y_r;
       const int mcol = min(m0 + src_slot(y_s, lr) * 8, a.Mp - 8);
-      const u16* src = a.dy + (long)(is_row + lr) * a.Mp + mcol;
-      glds16(src, dst + wave * 1024);
-      glds16(src + a.dy_plane, dst + YBYTES + wave * 1024);
+      const unsigned off = (unsigned)(((long)(is_row + lr) * a.Mp + mcol) * 2);
+      dma(dy_hi, off, dst + wave * 1024);
+      dma(dy_lo, off, dst + YBYTES + wave * 1024);
     }
 #pragma unroll
     for (int q = 0; q < (XPIECES + 7) / 8; ++q) {
@@ -460,9 +471,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
         int gr = is_row - PAD + lr;
         gr = gr < 0 ? 0 : (gr > last_row ? last_row : gr);
         const int ccol = min(c0 + src_slot(x_s, lr) * 8, a.Cp - 8);
-        const u16* src = a.x + (long)gr * a.Cp + ccol;
-        glds16(src, dst + 2 * YBYTES + p * 1024);
-        glds16(src + a.x_plane, dst + 2 * YBYTES + XBYTES + p * 1024);
+        const unsigned off = (unsigned)(((long)gr * a.Cp + ccol) * 2);
+        dma(x_hi, off, dst + 2 * YBYTES + p * 1024);
+        dma(x_lo, off, dst + 2 * YBYTES + XBYTES + p * 1024);
       }
     }
     is_row += 32;
@@ -483,7 +494,6 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
     xseg[cf] = (cb & 7) << 5;
     xline[cf] = (cb >> 3) * 256;
   }
-  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds;
 
   f32x4 acc[KW][4][NCF];
 #pragma unroll
@@ -492,50 +502,109 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NCF; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dY (hi + lo): the workgroups of c-tile 0 multiply their dY fragments by an all-ones
+  // operand as well (one wave per 64 m), instead of a separate pass re-reading dY
+  const bool do_bias = a.bias_partial != nullptr && c0 == 0 && (wave & 3) == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_raw);
+  // Opaque from here on: a known constant would be re-materialised by VALU moves right in front of each use, and the
+  // compiler inserts the VALU-write -> MFMA-read wait states only for MFMAs it can see (the ones below are inline asm;
+  // observed: wrong bias sums in the KW = 1 instantiation, where register pressure triggers the re-materialisation).
+  asm volatile("" : "+v"(ones));
 
+  // Fragment halves as the transposing reads return them.  Same phase structure as the convolution above: a K-tile
+  // (32 rows) is hi*hi, hi*lo, [barrier], lo*hi; the barrier sits between phases whose operands are in registers,
+  // the lo fragments are read during phase 1, the next K-tile's hi fragments during phase 3 (A hi and the X set that
+  // phase 2 has finished with are dead by then), and the two X fragment sets swap roles from one K-tile to the next.
+  bf16x8_t ah[4], al[4], b0[KW][NCF], b1[KW][NCF];
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+  // two transposing reads (k rows r..r+3 and r+16..r+19 of one 16-column block) -> one 8-element k fragment; through
+  // the builtin the two halves land directly in the halves of the fragment's register tuple (no copies)
+#define WX_TR(DST, BYTE_OFF, ROW_BYTES)                                                                              \
+  {                                                                                                                  \
+    const s16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(lds + (BYTE_OFF)));                    \
+    const s16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(lds + (BYTE_OFF) + 16 * (ROW_BYTES))); \
+    DST = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));                  \
+  }
+#define WX_RDA(DST, STAGE, PLANE, MI) WX_TR(DST[MI], (STAGE) * STAGE_B + (PLANE) * YBYTES + (ybase ^ yseg[MI]), YRB)
+#define WX_RDB(DST, STAGE, PLANE, TP, CF) \
+  WX_TR(DST[TP][CF], (STAGE) * STAGE_B + 2 * YBYTES + (PLANE) * XBYTES + ((xbase[TP] ^ xseg[CF]) + xline[CF]), XRB)
+  // MFMAs of one m-fragment against every (tap, c-fragment) of an X set (tied asm: see the convolution kernel)
+#define WX_MM(A, B, MI)                                                                                    \
+  _Pragma("unroll") for (int tp = 0; tp < KW; ++tp)                                                        \
+  _Pragma("unroll") for (int cf = 0; cf < NCF; ++cf)                                                       \
+      asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[tp][MI][cf]) : "v"(A[MI]), "v"(B[tp][cf]));
+  // the bias MFMAs exist only in the loop the c-tile-0 waves run: a per-use `if (do_bias)` around inline asm makes hipcc
+  // carry copies of the accumulators across every branch (31 v_mov_b64 each, in every wave)
+#define WX_BIAS_ON(A, MI) asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[MI]) : "v"(A[MI]), "v"(ones));
+#define WX_BIAS_OFF(A, MI)
+#define WX_SB __builtin_amdgcn_sched_barrier(0);
+  constexpr int STAGE_B = STAGE;
+
+  // one K-tile in stage S; BX = X hi fragments (already in registers), BY receives X lo, then the next tile's X hi
+#define WX_TILE(S, BX, BY, MORE, WX_BIAS)                                                                         \
+  /* phase 1: hi*hi; meanwhile X lo -> BY and dY lo -> al */                                               \
+  WX_MM(ah, BX, 0) WX_BIAS(ah, 0) WX_SB                                                                    \
+  _Pragma("unroll") for (int tp = 0; tp < KW; ++tp) _Pragma("unroll") for (int cf = 0; cf < NCF; ++cf) WX_RDB(BY, S, 1, tp, cf) \
+  WX_SB WX_MM(ah, BX, 1) WX_BIAS(ah, 1) WX_SB                                                              \
+  WX_RDA(al, S, 1, 0) WX_RDA(al, S, 1, 1) WX_RDA(al, S, 1, 2) WX_RDA(al, S, 1, 3)                          \
+  WX_SB WX_MM(ah, BX, 2) WX_BIAS(ah, 2) WX_MM(ah, BX, 3) WX_BIAS(ah, 3) WX_SB                              \
+  /* phase 2: hi*lo */                                                                                     \
+  WX_MM(ah, BY, 0) WX_MM(ah, BY, 1) WX_MM(ah, BY, 2) WX_MM(ah, BY, 3) WX_SB                                \
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
+  __builtin_amdgcn_s_barrier();                                                                            \
+  /* phase 3: lo*hi; meanwhile the DMA of K-tile t+2 into this stage and the next tile's hi fragments */   \
+  if (MORE) issue(S);                                                                                      \
+  WX_MM(al, BX, 0) WX_BIAS(al, 0) WX_SB                                                                    \
+  WX_RDA(ah, (S) ^ 1, 0, 0) WX_RDA(ah, (S) ^ 1, 0, 1) WX_RDA(ah, (S) ^ 1, 0, 2) WX_RDA(ah, (S) ^ 1, 0, 3)  \
+  WX_SB WX_MM(al, BX, 1) WX_BIAS(al, 1) WX_SB                                                              \
+  _Pragma("unroll") for (int tp = 0; tp < KW; ++tp) _Pragma("unroll") for (int cf = 0; cf < NCF; ++cf) WX_RDB(BY, (S) ^ 1, 0, tp, cf) \
+  WX_SB WX_MM(al, BX, 2) WX_BIAS(al, 2) WX_MM(al, BX, 3) WX_BIAS(al, 3) WX_SB
+
+  const bool extra = (XPIECES % 8 != 0) && (wave < XPIECES % 8);   // this wave stages one more X piece per K-tile
   if (n > 0) {
     issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < n; ++t) {
-      const int stage = t & 1;
-      if (t + 1 < n) issue(stage ^ 1);
-      const unsigned ys = lds0 + stage * STAGE, xs = ys + 2 * YBYTES;
-      u64x ahl[4], ahh[4], all_[4], alh[4], bhl[KW][NCF], bhh[KW][NCF], bll[KW][NCF], blh[KW][NCF];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        tr_issue<YRB>(ys + (ybase ^ yseg[mi]), ahl[mi], ahh[mi]);
-        tr_issue<YRB>(ys + YBYTES + (ybase ^ yseg[mi]), all_[mi], alh[mi]);
-      }
-#pragma unroll
-      for (int tp = 0; tp < KW; ++tp)
-#pragma unroll
-        for (int cf = 0; cf < NCF; ++cf) {
-          const unsigned off = (xbase[tp] ^ xseg[cf]) + xline[cf];
-          tr_issue<XRB>(xs + off, bhl[tp][cf], bhh[tp][cf]);
-          tr_issue<XRB>(xs + XBYTES + off, bll[tp][cf], blh[tp][cf]);
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const bf16x8_t ah = tr_join(ahl[mi], ahh[mi]), al = tr_join(all_[mi], alh[mi]);
-#pragma unroll
-        for (int tp = 0; tp < KW; ++tp)
-#pragma unroll
-          for (int cf = 0; cf < NCF; ++cf) {
-            const bf16x8_t bh = tr_join(bhl[tp][cf], bhh[tp][cf]), bl = tr_join(bll[tp][cf], blh[tp][cf]);
-            f32x4 c = acc[tp][mi][cf];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-            acc[tp][mi][cf] = c;
-          }
-      }
+    if (n > 1) issue(1);
+    if (n > 1) {
+      if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ((XPIECES + 7) / 8) + 2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (XPIECES / 8) + 2) : "memory");
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
     }
+    __builtin_amdgcn_s_barrier();
+    WX_RDA(ah, 0, 0, 0) WX_RDA(ah, 0, 0, 1) WX_RDA(ah, 0, 0, 2) WX_RDA(ah, 0, 0, 3)
+#pragma unroll
+    for (int tp = 0; tp < KW; ++tp)
+#pragma unroll
+      for (int cf = 0; cf < NCF; ++cf) WX_RDB(b0, 0, 0, tp, cf)
+    if (do_bias) {
+      for (int t = 0; t < n; t += 2) {
+        WX_TILE(0, b0, b1, t + 2 < n, WX_BIAS_ON)
+        WX_TILE(1, b1, b0, t + 3 < n, WX_BIAS_ON)
+      }
+    } else {
+      for (int t = 0; t < n; t += 2) {
+        WX_TILE(0, b0, b1, t + 2 < n, WX_BIAS_OFF)
+        WX_TILE(1, b1, b0, t + 3 < n, WX_BIAS_OFF)
+      }
+    }
+    // the compiler's hazard recogniser does not see inside the asm MFMAs: cover the MFMA-result -> VALU-read wait
+    // states by hand before the accumulators are stored
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   }
+#undef WX_TILE
+#undef WX_SB
+#undef WX_BIAS_ON
+#undef WX_BIAS_OFF
+#undef WX_MM
+#undef WX_TR
+#undef WX_RDB
+#undef WX_RDA
 
   const int li = lane & 15, kq = lane >> 4;
   float* out = a.partial + (long)split * KW * a.M * a.C;
@@ -551,6 +620,25 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
           const int c = c0 + wc0 + cf * 16 + li;
           if (m < a.M && c < a.C) out[((long)t * a.M + m) * a.C + c] = acc[t][mi][cf][r];
         }
+  if (do_bias && li == 0) {      // every column j of D holds the same sum; lane li = 0 writes it
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm0 + mi * 16 + kq * 4 + r;
+        if (m < a.Mp) a.bias_partial[(long)split * a.Mp + m] = accb[mi][r];
+      }
+  }
+}
+
+// dbias[m] (+)= sum_s bias_partial[s][m], fixed order
+static __global__ __launch_bounds__(256) void wgrad_x3_bias_reduce_kernel(const float* bp, float* dbias, int splits, int Mp, int M,
+                                                                          int accumulate) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += bp[(long)k * Mp + m];
+  dbias[m] = accumulate ? dbias[m] + s : s;
 }
 
 __global__ __launch_bounds__(256) void ncl_to_nlc_x3_kernel(const float* x, u16* y, long plane, int B, int C, int L, int Cp,
@@ -617,52 +705,6 @@ __global__ __launch_bounds__(256) void relu_mask_x3_kernel(const u16* dy, const 
   }
 }
 
-__global__ __launch_bounds__(256) void bias_grad_x3_partial_kernel(const u16* dy, long plane, float* partial, int rows, int Mp,
-                                                                   int rows_per_split) {
-  const int groups = Mp / 8;
-  const int gpb = groups < 256 ? groups : 256;
-  const int rsub = 256 / gpb;
-  const int gi = threadIdx.x % gpb, rp = threadIdx.x / gpb;
-  const int grp = blockIdx.x * gpb + gi;
-  const int rb = blockIdx.y * rows_per_split, re = min(rows, rb + rows_per_split);
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (grp < groups && rp < rsub)
-    for (int r = rb + rp; r < re; r += rsub) {
-      const u16x8 vh = *(const u16x8*)(dy + (long)r * Mp + grp * 8), vl = *(const u16x8*)(dy + plane + (long)r * Mp + grp * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += bf2f(vh[e]) + bf2f(vl[e]);
-    }
-  __shared__ float red[256][9];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
-  __syncthreads();
-  if (rp == 0 && grp < groups) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = 0.f;
-      for (int k = 0; k < rsub; ++k) t += red[k * gpb + gi][e];
-      partial[(long)blockIdx.y * Mp + grp * 8 + e] = t;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void bias_grad_x3_final_kernel(const float* partial, float* dbias, int splits, int Mp, int M,
-                                                                  int accumulate) {
-  // 32 channels x 8 split-phases per workgroup (coalesced along m, 8-way parallel along the splits), fixed order
-  const int mi = threadIdx.x & 31, ph = threadIdx.x >> 5;
-  const int m = blockIdx.x * 32 + mi;
-  float s = 0.f;
-  if (m < M)
-    for (int k = ph; k < splits; k += 8) s += partial[(long)k * Mp + m];
-  __shared__ float red[8][32];
-  red[ph][mi] = s;
-  __syncthreads();
-  if (ph == 0 && m < M) {
-    const float t = ((red[0][mi] + red[1][mi]) + (red[2][mi] + red[3][mi])) + ((red[4][mi] + red[5][mi]) + (red[6][mi] + red[7][mi]));
-    dbias[m] = accumulate ? dbias[m] + t : t;
-  }
-}
-
 template <int KW, int NCF>
 static constexpr int wgrad_x3_lds() {
   return 2 * (2 * 32 * 256 + 2 * (KW == 1 ? 32 : 36) * (4 * NCF * 16 * 2));
@@ -679,7 +721,7 @@ static int wgrad_x3_splits(int total_rows, int tiles, int* chunks_per_split) {
   return (nchunks + cps - 1) / cps;
 }
 
-constexpr int X3_BIAS_SPLITS = 256;
+constexpr int X3_BIAS_SPLITS = 64;     // upper bound of the split count (wgrad_x3_splits)
 
 }  // namespace alvq
 
@@ -782,9 +824,11 @@ extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw
   hipStream_t s = (hipStream_t)stream;
   const int rows = (int)alvq_nlc_rows(B, L);
   const int ct = KW == 3 ? 128 : 256;
-  WgradX3Args a{(const u16*)dy, (const u16*)x, (float*)workspace, nlc_plane_elems(B, L, M), nlc_plane_elems(B, L, C),
+  WgradX3Args a{(const u16*)dy, (const u16*)x, (float*)workspace, nullptr, nlc_plane_elems(B, L, M), nlc_plane_elems(B, L, C),
                 pad_to(M, 64), pad_to(C, 64), M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, rows};
   a.splits = wgrad_x3_splits(rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
+  if (dbias) a.bias_partial = bpart;
   static DeviceOnce attr;
   if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16x3_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_x3_lds<3, 2>());
@@ -796,16 +840,8 @@ extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw
   int rc = check_launch("alvq_conv1d_wgrad_bf16x3");
   if (rc) return rc;
   wgrad_reduce_launch((const float*)workspace, dw, a.splits, KW, M, C, w_layout, accumulate, s);
-  rc = check_launch("alvq_conv1d_wgrad_bf16x3/reduce");
-  if (rc) return rc;
-  if (dbias) {
-    float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
-    const int Mp = pad_to(M, 64), bs = X3_BIAS_SPLITS, rps = (rows + bs - 1) / bs;
-    hipLaunchKernelGGL(bias_grad_x3_partial_kernel, dim3((Mp / 8 + 255) / 256, bs), dim3(256), 0, s, (const u16*)dy, a.dy_plane,
-                       bpart, rows, Mp, rps);
-    hipLaunchKernelGGL(bias_grad_x3_final_kernel, dim3((M + 31) / 32), dim3(256), 0, s, (const float*)bpart, dbias, bs, Mp, M,
-                       accumulate);
-    rc = check_launch("alvq_conv1d_wgrad_bf16x3/bias");
-  }
-  return rc;
+  if (dbias)
+    hipLaunchKernelGGL(wgrad_x3_bias_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, a.splits,
+                       a.Mp, M, accumulate);
+  return check_launch("alvq_conv1d_wgrad_bf16x3/reduce");
 }

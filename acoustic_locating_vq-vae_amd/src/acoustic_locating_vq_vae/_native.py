@@ -77,6 +77,9 @@ _SIGNATURES = {
     "alvq_conv1d_bf16x3": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p]),
     "alvq_conv1d_wgrad_bf16x3_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_bf16x3": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
+    "alvq_onehot_to_index_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
+    "alvq_embedding_bag_fwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 4 + [_c_void_p]),
+    "alvq_embedding_bag_bwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 5 + [_c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -301,6 +304,41 @@ def onehot(idx, K):
     enc = torch.empty((N, K), device=idx.device, dtype=torch.float32)
     _check(lib().alvq_onehot_f32(_ptr(idx, torch.int64, "idx"), _ptr(enc), N, K, _stream()), "alvq_onehot_f32")
     return enc
+
+
+def onehot_to_index(enc):
+    """(rows, K) fp32 one-hot rows -> (idx int32 [rows], flag int32 [1]); flag != 0 iff some row is not exactly one-hot."""
+    rows, K = enc.shape
+    idx = torch.empty((rows,), device=enc.device, dtype=torch.int32)
+    flag = torch.empty((1,), device=enc.device, dtype=torch.float32)
+    fill_(flag, 0.0)                                 # bit pattern 0 == int 0
+    flag = flag.view(torch.int32)
+    _check(lib().alvq_onehot_to_index_f32(_ptr(enc, name="encodings"), idx.data_ptr(), flag.data_ptr(), rows, K, _stream()),
+           "alvq_onehot_to_index_f32")
+    return idx, flag
+
+
+def embedding_bag_fwd(W, bias, idx, L, K):
+    """out (B, M) = bias + sum_l W[:, l*K + idx[b, l]];  W (M, L*K) fp32, idx (B, L) int32."""
+    B = idx.shape[0]
+    M = W.shape[0]
+    if W.shape[1] != L * K or tuple(idx.shape) != (B, L):
+        raise RuntimeError("embedding_bag_fwd: W %s / idx %s do not match L=%d, K=%d" % (tuple(W.shape), tuple(idx.shape), L, K))
+    out = torch.empty((B, M), device=W.device, dtype=torch.float32)
+    _check(lib().alvq_embedding_bag_fwd_f32(_ptr(W, name="W"), _ptr(bias, name="bias"), _ptr(idx, torch.int32, "idx"), _ptr(out),
+                                            B, L, K, M, _stream()), "alvq_embedding_bag_fwd_f32")
+    return out
+
+
+def embedding_bag_bwd(dz, idx, L, K, want_bias=True):
+    """(dW (M, L*K) dense with the touched columns filled, dbias (M,)) from dz (B, M) and idx (B, L) int32."""
+    B, M = dz.shape
+    dW = torch.empty((M, L * K), device=dz.device, dtype=torch.float32)
+    fill_(dW, 0.0)
+    db = torch.empty((M,), device=dz.device, dtype=torch.float32) if want_bias else None
+    _check(lib().alvq_embedding_bag_bwd_f32(_ptr(dz, name="dz"), _ptr(idx, torch.int32, "idx"), _ptr(dW), _ptr(db), B, L, K, M, 0,
+                                            _stream()), "alvq_embedding_bag_bwd_f32")
+    return dW, db
 
 
 # ----------------------------------------------------------------------------------------------- misc

@@ -8,6 +8,17 @@
 A "step" = standardise -> encoder -> pre-VQ conv -> VQ -> decoder -> MSE -> backward -> [one RCCL all-reduce of
 the flat gradient buffer] -> Adam, on a synthetic (B,201,500) batch already resident in HBM (speech ctor of
 scripts/train_speech.py:152-153, B=64 per GPU, weak scaling).  Prints ONE JSON line on rank 0.
+
+What the line holds (N=1):
+  value / roofline ........ the headline mode (--dtype, default bf16 = what configs[1] literally names), hipGraph replay;
+                            `roofline` is KERNEL-ONLY (the dominant conv kernel, live HIP events over an instrumented
+                            eager pass); `step_frac_of_peak` is the whole step's model FLOPs against the same peak
+  parity .................. per mode: codebook-index agreement and z / recon / loss errors MEASURED IN THIS RUN on the
+                            default-config golden made by the real reference (tests/golden/g3_speech.npz)
+  north_star .............. the mode that carries the parity claim (bit-exact indices, 1e-3 forward): its throughput,
+                            x CPU, kernel roofline against ITS structural peak, and its parity numbers
+  f32_parity_mode, bf16x3_parity_mode, script_loop_mode, vq_stress, rir_config, echoed_config ... secondary lines
+  cpu_baseline ............ the oracle port timed on the host cores (B=4, BASELINE configs[0])
 """
 import argparse
 import json
@@ -17,7 +28,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "acoustic_locating_vq-vae_amd")
-for _p in (ROOT, PKG, os.path.join(PKG, "src")):
+for _p in (ROOT, PKG, os.path.join(PKG, "src"), os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
@@ -27,10 +38,18 @@ import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 matrix rate (= vector rate)
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (NOT the 2:1-sparsity headline)
-PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS}
+# Peak of ALGORITHMIC FLOP/s per mode.  bf16x3 issues three bf16 MFMAs per algorithmic product (hi*hi + hi*lo +
+# lo*hi), so its structural ceiling is a third of the bf16 matrix peak.
+PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0}
+PEAK_NOTE = {"f32": "exact-fp32 MFMA peak 157.3 TFLOP/s", "bf16": "dense bf16 MFMA peak 2500 TFLOP/s",
+             "bf16x3": "2500/3 = 833.3 TFLOP/s algorithmic: three bf16 MFMAs per product"}
 CONV_FAMILIES = {"f32": ("conv1d_f32_kernel", "conv1d_wgrad_f32_kernel"),
                  "bf16": ("conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel", "conv1d_wgrad_bf16_v2_kernel"),
                  "bf16x3": ("conv1d_bf16x3_kernel", "conv1d_wgrad_bf16x3_kernel")}
+MODE_TEXT = {"bf16": "bf16 storage + bf16 MFMA, fp32 accumulate / VQ / losses / master weights",
+             "bf16x3": "split-bf16 (hi+lo planes, 3 bf16 MFMAs per product, fp32 accumulate)",
+             "f32": "fp32 storage + exact-fp32 MFMA"}
+NORTH_STAR_MODE = "bf16x3"        # the mode whose parity is bit-exact indices / <=1e-3 forward AND that clears 100x CPU
 SPEECH_CFG = (201, 1024, 128, 3, 1024, 0.25, 1024)          # scripts/train_speech.py:152-153
 RIR_CFG = (500, 1024, 64, 2, 64, 0.25, 1024)                # scripts/train_rir.py:147-149
 
@@ -86,10 +105,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"],
                     help="bf16: BASELINE configs[1] (bf16 storage/MFMA, fp32 accumulate+master weights); f32: parity mode "
                          "on the exact-fp32 MFMA; bf16x3: split-bf16 parity mode (3 bf16 MFMAs per product)")
-    ap.add_argument("--no-f32-line", action="store_true", help="skip the secondary fp32 parity-mode measurement")
+    ap.add_argument("--no-secondary", "--no-f32-line", dest="no_secondary", action="store_true",
+                    help="only the headline line (skip parity modes, script loop, VQ stress, rir / echoed configs)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the golden parity measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,39 +137,26 @@ def main():
     from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
     from acoustic_locating_vq_vae.train_step import Trainer
 
-    _ops.set_compute_dtype(args.dtype)
-    torch.manual_seed(0)                         # identical init on every rank (also broadcast by Trainer)
-    np.random.seed(1234 + rank)                  # jitter: per-rank numpy stream
-    B = args.batch
-    if args.config == "speech":
-        cfg, L, oc = SPEECH_CFG, 500, None
-        model = ConvolutionalVQVAE(*cfg).cuda()
-        kind = "speech"
-    elif args.config == "rir":
-        cfg, L, oc = RIR_CFG, 201, 1
-        model = ConvolutionalVQVAE(*cfg, use_jitter=False, out_channels=1).cuda()
-        kind = "rir"
-    else:
-        # scripts/train_echoed_speech.py:45-46 from two freshly initialised sub-models (no checkpoints ship)
-        from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
-        cfg, L, oc = SPEECH_CFG, 500, None
-        rir = ConvolutionalVQVAE(*RIR_CFG, use_jitter=False, out_channels=1)
-        sp = ConvolutionalVQVAE(*SPEECH_CFG)
-        model = EchoedSpeechReconModel(rir, sp, 201, 1024, 2, 1024, True).cuda()
-        kind = "echoed"
-    model.train()
-    trainer = Trainer(model, kind)
-    g = torch.Generator(device="cuda")
-    g.manual_seed(100 + rank)
-    raw = torch.randn(B, 201, 500, device="cuda", generator=g)      # synthetic spectrogram batch, resident in HBM
-    wiener = torch.randn(B, 201, device="cuda", generator=g) if kind == "rir" else None
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(steps, warmup, use_timer):
+    def make(kind):
+        """Model + per-spectrogram FLOPs of one BASELINE config, fresh init (seeded identically on every rank)."""
+        torch.manual_seed(0)
+        if kind == "speech":
+            return ConvolutionalVQVAE(*SPEECH_CFG).cuda().train(), SPEECH_CFG, algorithmic_gflop_per_spectrogram(SPEECH_CFG, 500)
+        if kind == "rir":
+            m = ConvolutionalVQVAE(*RIR_CFG, use_jitter=False, out_channels=1).cuda().train()
+            return m, RIR_CFG, algorithmic_gflop_per_spectrogram(RIR_CFG, 201, 1)
+        # scripts/train_echoed_speech.py:45-46 from two freshly initialised sub-models (no checkpoints ship)
+        from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
+        rir = ConvolutionalVQVAE(*RIR_CFG, use_jitter=False, out_channels=1)
+        sp = ConvolutionalVQVAE(*SPEECH_CFG)
+        return EchoedSpeechReconModel(rir, sp, 201, 1024, 2, 1024, True).cuda().train(), SPEECH_CFG, 61.73   # SURVEY 8(d)
+
+    def measure(trainer, raw, wiener, steps, warmup, use_timer):
         for _ in range(warmup):
             out = trainer.step(raw, wiener)
         barrier()
@@ -170,7 +178,7 @@ def main():
         assert np.isfinite(last), "non-finite loss"
         return dt, last, (timer.summary() if timer is not None else None)
 
-    def roofline(summ, dtype, steps):
+    def roofline(summ, dtype):
         # the dominant kernel = the conv kernel with the largest share of the timed region
         fam = max((f for f in CONV_FAMILIES[dtype] if f in summ), key=lambda f: summ[f][1])
         n, secs, flops = summ[fam]
@@ -179,7 +187,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(fam)
-        return {"bound": "mfma", "kernel": fam, "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s",
+        return {"bound": "mfma", "scope": "kernel-only (dominant conv kernel, not the whole step)", "kernel": fam,
+                "achieved": ach, "peak": PEAK[dtype], "peak_is": PEAK_NOTE[dtype], "unit": "TFLOP/s",
                 "frac": ach / PEAK[dtype], "traffic": traffic, "launches": n, "avg_launch_ms": 1e3 * secs / n,
                 "algorithmic_gflop_per_launch": flops / n / 1e9}
 
@@ -187,71 +196,123 @@ def main():
         return {k: {"launches": v[0], "ms_per_step": 1e3 * v[1] / steps, "tflops": (v[2] / v[1] / 1e12) if v[1] > 0 else None}
                 for k, v in summ.items()}
 
-    graph = "off"
-    if not args.no_graph:
-        try:
-            trainer.capture(raw, wiener)
-            graph = "hipGraph replay"
-        except Exception as exc:                           # fall back to eager launches, and say so
-            graph = "off (capture failed: %s)" % (str(exc).splitlines()[0][:120],)
+    def run_config(kind, dtype, B, steps, warmup, graph=True, timer=True, grad_buckets=None):
+        """One (config, mode) measurement on a fresh model: K timed steps (graph replay when captured); the per-kernel
+        durations behind `roofline` come from an instrumented eager pass of the same steps right after, because HIP
+        events cannot bracket kernels inside a replay."""
+        _ops.set_compute_dtype(dtype)
+        np.random.seed(1234 + rank)                  # jitter: per-rank numpy stream (SURVEY 8e)
+        model, cfg, gf = make(kind)
+        trainer = Trainer(model, kind, grad_buckets=grad_buckets)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(100 + rank)
+        raw = torch.randn(B, 201, 500, device="cuda", generator=g)      # synthetic spectrogram batch, resident in HBM
+        wiener = torch.randn(B, 201, device="cuda", generator=g) if kind == "rir" else None
+        launch = "eager"
+        if graph:
+            try:
+                trainer.capture(raw, wiener)
+                launch = "hipGraph replay"
+            except Exception as exc:                           # fall back to eager launches, and say so
+                launch = "eager (capture failed: %s)" % (str(exc).splitlines()[0][:120],)
+                trainer._graph = None
+        elapsed, loss, summ = measure(trainer, raw, wiener, steps, warmup, timer and trainer._graph is None)
+        if summ is None and timer:
+            g_saved, gl_saved = trainer._graph, getattr(trainer, "_graph_late", None)
             trainer._graph = None
-    # timed region: K steps (graph replay when captured).  HIP events cannot bracket kernels inside a replay,
-    # so the per-kernel durations behind `roofline` come from an instrumented eager pass of the same K steps
-    # on the same model/batch right after it.
-    elapsed, loss, summ = measure(args.steps, args.warmup, (not args.no_kernel_timer) and trainer._graph is None)
-    if summ is None and not args.no_kernel_timer:
-        g_saved, trainer._graph = trainer._graph, None
-        _, _, summ = measure(args.steps, 1, True)
-        trainer._graph = g_saved
+            _, _, summ = measure(trainer, raw, wiener, min(steps, 10), 1, True)
+            trainer._graph, trainer._graph_late = g_saved, gl_saved
+            summ_steps = min(steps, 10)
+        else:
+            summ_steps = steps
+        value = world * B * steps / elapsed
+        res = {"value": value, "unit": "spectrograms/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+               "dtype": dtype, "launch": launch, "model_tflops": value * gf / 1e3,
+               "step_frac_of_peak": value * gf / 1e3 / world / PEAK[dtype], "final_loss": loss,
+               "allreduce_calls_per_step": (0 if world == 1 else (2 if trainer._buckets else 1))}
+        if summ is not None:
+            res["roofline"] = roofline(summ, dtype)
+            res["kernel_families"] = families(summ, summ_steps)
+        del trainer, model
+        torch.cuda.empty_cache()
+        return res, cfg, gf
 
+    def parity(mode):
+        """The current build's parity on the default-config golden (2 x (201,500), closed-form weights; made by the
+        real reference).  The oracle package supplies the weight/input generators only -- a checker, never timed."""
+        import g3_cases
+        _ops.set_compute_dtype(mode)
+        r = g3_cases.run("speech")
+        keep = ("idx_total", "idx_mismatches", "idx_agree", "mismatch_gap_max", "z_rel_max", "z_rel_l2", "recon_rel_max",
+                "recon_rel_l2", "vq_loss_rel", "recon_error_rel", "grad_rel_max", "grad_rel_l2_median")
+        out = {k: r[k] for k in keep}
+        out["golden"] = "tests/golden/g3_speech.npz (speech ctor, B=2, made by the reference)"
+        return out
+
+    kind, B = args.config, args.batch
+    head, cfg, gf = run_config(kind, args.dtype, B, args.steps, args.warmup, graph=not args.no_graph,
+                               timer=not args.no_kernel_timer)
+    line = None
     if rank == 0:
-        gf = 61.73 if kind == "echoed" else algorithmic_gflop_per_spectrogram(cfg, L, oc)
-        value = world * B * args.steps / elapsed
         line = {
             "metric": "spectrograms/sec (train step), %s VQ-VAE default config" % ("echoed-speech" if kind == "echoed" else kind),
-            "value": value, "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": head["value"], "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s VQ-VAE train step (fwd+bwd+Adam), ctor %s, B=%d per GPU x (%s), %s, jitter %s"
-                                   % (kind, list(cfg), B, "500,201" if kind == "rir" else "201,500",
-                                      {"bf16": "bf16 storage + bf16 MFMA, fp32 accumulate / VQ / losses / master weights",
-                                       "bf16x3": "split-bf16 (hi+lo planes, 3 bf16 MFMAs per product, fp32 accumulate)",
-                                       "f32": "fp32 storage + exact-fp32 MFMA"}[args.dtype],
+                                   % (kind, list(cfg), B, "500,201" if kind == "rir" else "201,500", MODE_TEXT[args.dtype],
                                       "off" if kind == "rir" else "on"),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "algorithmic_gflop_per_spectrogram": gf},
-            "model_tflops": value * gf / 1e3,
-            "final_loss": loss,
-            "launch": graph,
+            "model_tflops": head["model_tflops"], "step_frac_of_peak": head["step_frac_of_peak"],
+            "final_loss": head["final_loss"], "launch": head["launch"],
+            "allreduce_calls_per_step": head["allreduce_calls_per_step"],
         }
-        if summ is not None:
-            line["roofline"] = roofline(summ, args.dtype, args.steps)
-            line["kernel_families"] = families(summ, args.steps)
-    if args.dtype == "bf16" and not args.no_f32_line:
-        # secondary lines on the same model and batch (eager launches; the bf16 graph does not apply):
-        #   f32    -- the parity mode on the exact-fp32 MFMA (1e-3 / bit-exact claims are made for this one);
-        #   bf16x3 -- the split-bf16 parity mode (fp32-grade forward parity at 3 bf16 MFMAs per product)
-        for mode, key in (("f32", "f32_parity_mode"), ("bf16x3", "bf16x3_parity_mode")):
-            _ops.set_compute_dtype(mode)
-            g_saved, trainer._graph = trainer._graph, None
-            s2 = max(3, min(5, args.steps))
-            e2, l2, _ = measure(s2, 2, False)                 # the rate: no per-launch events in the timed region
-            summ2 = None if args.no_kernel_timer else measure(s2, 0, True)[2]   # the roofline: instrumented pass
-            trainer._graph = g_saved
-            _ops.set_compute_dtype(args.dtype)
-            if rank == 0:
-                v2 = world * B * s2 / e2
-                line[key] = {"value": v2, "unit": "spectrograms/s", "ms_per_step": 1e3 * e2 / s2, "steps": s2,
-                             "model_tflops": v2 * gf / 1e3, "launch": "eager"}
-                if summ2 is not None:
-                    line[key]["roofline"] = roofline(summ2, mode, s2)
-    if rank == 0 and world == 1 and kind == "speech" and not args.no_f32_line:
+        for k in ("roofline", "kernel_families"):
+            if k in head:
+                line[k] = head[k]
+
+    secondary = not args.no_secondary
+    if world > 1 and secondary and kind != "echoed":
+        # gradient exchange, measured both ways on this node: the north star's single all-reduce (the default) and the
+        # two-span variant whose first span overlaps the encoder's backward
+        alt, _, _ = run_config(kind, args.dtype, B, max(3, min(10, args.steps)), 2, graph=not args.no_graph, timer=False,
+                               grad_buckets=2)
+        if rank == 0:
+            line["grad_exchange"] = {
+                "default": {"allreduce_calls_per_step": head["allreduce_calls_per_step"], "value": head["value"],
+                            "ms_per_step": head["ms_per_step"]},
+                "two_spans": {"allreduce_calls_per_step": alt["allreduce_calls_per_step"], "value": alt["value"],
+                              "ms_per_step": alt["ms_per_step"]}}
+
+    if kind == "speech" and secondary:
+        modes = {}
+        for mode in ("bf16x3", "f32"):
+            if mode == args.dtype:
+                modes[mode] = head
+                continue
+            steps2 = max(3, min(10 if mode == "bf16x3" else 5, args.steps))
+            modes[mode], _, _ = run_config("speech", mode, B, steps2, 2, graph=not args.no_graph,
+                                           timer=not args.no_kernel_timer)
+        if rank == 0:
+            for mode, key in (("f32", "f32_parity_mode"), ("bf16x3", "bf16x3_parity_mode")):
+                if mode != args.dtype:
+                    line[key] = {k: v for k, v in modes[mode].items() if k != "kernel_families"}
+            line["_ns_src"] = modes.get(NORTH_STAR_MODE, head if args.dtype == NORTH_STAR_MODE else None)
+
+    if rank == 0 and world == 1 and kind == "speech" and not args.no_parity:
+        line["parity"] = {m: parity(m) for m in (["bf16", "bf16x3", "f32"] if secondary else [args.dtype])}
+        _ops.set_compute_dtype(args.dtype)
+
+    if rank == 0 and world == 1 and kind == "speech" and secondary:
         # what scripts/train_speech.py itself gets when its imports resolve to this build: the script's own loop body
         # (torch ops for |x| / standardise / MSE, loss.backward(), torch.optim.Adam) on the module API -- no
         # Trainer, no flat buffers, no graph.  Same model config, batch and dtype; eager launches.
         import torch.nn.functional as F
-        m2 = ConvolutionalVQVAE(*cfg).cuda().train()
+        _ops.set_compute_dtype(args.dtype)
+        m2 = ConvolutionalVQVAE(*SPEECH_CFG).cuda().train()
         opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3, amsgrad=False)
+        raw = torch.randn(B, 201, 500, device="cuda")
 
         def script_step():
             x = torch.abs(raw)
@@ -271,12 +332,64 @@ def main():
         torch.cuda.synchronize()
         e3 = time.perf_counter() - t0
         line["script_loop_mode"] = {"value": B * s3 / e3, "unit": "spectrograms/s", "ms_per_step": 1e3 * e3 / s3, "steps": s3,
+                                    "dtype": args.dtype,
                                     "launch": "eager, module API + torch.optim.Adam (train_speech.py:62-74,88-91)"}
-        del m2, opt2
+        del m2, opt2, raw
+        torch.cuda.empty_cache()
+
+        # BASELINE configs[3]: the VQ argmin kernel alone, codebook 4096 x 256, N = 512 * 500 rows
+        n_, k_, d_ = 256000, 4096, 256
+        g = torch.Generator(device="cuda").manual_seed(0)
+        xs, es = torch.randn(n_, d_, device="cuda", generator=g), torch.randn(k_, d_, device="cuda", generator=g)
+        for _ in range(2):
+            idx = N.vq_argmin(xs, es)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # current stream = launch stream
+        e0.record()
+        for _ in range(5):
+            idx = N.vq_argmin(xs, es)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        from oracle import vqvae_oracle as O
+        rows = torch.arange(0, n_, 997, device="cuda")
+        ok = bool(torch.equal(idx[rows].cpu(), O.vq_distances(xs[rows].cpu(), es.cpu()).argmin(dim=1)))
+        tf = 2.0 * n_ * k_ * d_ / ms / 1e9
+        line["vq_stress"] = {"workload": "alvq_vq_argmin_f32, x (256000,256) vs codebook (4096,256), N(0,1) (BASELINE configs[3])",
+                             "ms": ms, "tflops": tf, "peak": F32_MFMA_PEAK_TFLOPS, "frac": tf / F32_MFMA_PEAK_TFLOPS,
+                             "rows_per_s": n_ / ms * 1e3, "idx_bit_exact_on_sample": ok, "sample_rows": int(rows.numel()),
+                             "algorithmic_mbytes": (n_ * d_ * 4 + k_ * d_ * 4 + n_ * 8) / 1e6}
+        del xs, es, idx
+        torch.cuda.empty_cache()
+
+        # BASELINE configs[2] and [4] at their per-GPU batch (256/8 and 128/4 = 32), headline dtype, graph replay
+        for cfgname, key in (("rir", "rir_config"), ("echoed", "echoed_config")):
+            r, c2, gf2 = run_config(cfgname, args.dtype, 32, max(5, min(20, args.steps)), 3, graph=not args.no_graph, timer=False)
+            line[key] = {"workload": "%s train step, B=32 per GPU (BASELINE configs[%d] per-GPU share), %s"
+                                     % (cfgname, 2 if cfgname == "rir" else 4, args.dtype),
+                         "value": r["value"], "unit": "spectrograms/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                         "launch": r["launch"], "model_tflops": r["model_tflops"], "algorithmic_gflop_per_spectrogram": gf2}
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        ns = line.pop("_ns_src", None)
+        if ns is not None:
+            # the operating point that carries the north star's parity claim, in one place
+            blk = {"mode": NORTH_STAR_MODE, "what": MODE_TEXT[NORTH_STAR_MODE], "value": ns["value"], "unit": "spectrograms/s",
+                   "ms_per_step": ns["ms_per_step"], "launch": ns["launch"], "step_frac_of_peak": ns["step_frac_of_peak"]}
+            if "roofline" in ns:
+                blk["roofline_frac"] = ns["roofline"]["frac"]
+                blk["roofline_peak"] = ns["roofline"]["peak_is"]
+                blk["roofline_kernel"] = ns["roofline"]["kernel"]
+                blk["roofline_achieved_tflops"] = ns["roofline"]["achieved"]
+            if "cpu_baseline" in line:
+                blk["x_cpu"] = ns["value"] / line["cpu_baseline"]["value"]
+            if "parity" in line and NORTH_STAR_MODE in line["parity"]:
+                blk["parity"] = line["parity"][NORTH_STAR_MODE]
+            blk["targets"] = "north_star: >=100x CPU, >=40% of the relevant roofline, indices bit-exact, outputs within 1e-3"
+            line["north_star"] = blk
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

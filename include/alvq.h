@@ -270,6 +270,25 @@ int64_t alvq_conv1d_wgrad_bf16x3_workspace_bytes(int B, int C, int M, int L, int
 int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
                              int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
 
+/* ================================================================================================
+ * Location head: LocationModule.fc_1 = nn.Linear(L*K, M) on the flattened one-hot codes of a
+ * spectrogram (vq_vae/location_model/location_model.py:10,21; scripts/train_location.py:69-77 feeds it
+ * encodings.reshape(B, 201, 1024)).  On one-hot input the dense product is an embedding bag over the indices the
+ * quantiser produced: B*L*M gathered weights instead of a (B, L*K) x (L*K, M) GEMM against a 99.9 %-zero operand.
+ * ============================================================================================== */
+/* idx[row] = position of the single 1.0 in row `row` of encodings (rows, K); *not_onehot (device int, caller zeroes
+ * it) is OR-ed with 1 if any row is not exactly one-hot (then the caller must fall back to the dense product).
+ * Inverse of alvq_onehot_f32 for the value get_latent_representation returns (vector_quantizer.py:39-40,58). */
+int alvq_onehot_to_index_f32(const float* encodings, int32_t* idx, int* not_onehot, int64_t rows, int K, void* stream);
+/* out[b][m] = bias[m] + sum_l W[m][l*K + idx[b][l]]      W: (M, L*K) row-major (nn.Linear.weight), idx: (B, L),
+ * out: (B, M); sums in a fixed order.  Replaces F.linear at location_model.py:21 for one-hot x.  B*L <= 16384. */
+int alvq_embedding_bag_fwd_f32(const float* W, const float* bias, const int32_t* idx, float* out,
+                               int B, int L, int K, int M, void* stream);
+/* dW[m][l*K + idx[b][l]] += dz[b][m] for every (b, l) -- the caller zero-fills dW (M, L*K) first (alvq_fill_f32) --
+ * and dbias[m] (+)= sum_b dz[b][m].  One wave owns a weight row: no atomics, fixed order. */
+int alvq_embedding_bag_bwd_f32(const float* dz, const int32_t* idx, float* dW, float* dbias,
+                               int B, int L, int K, int M, int accumulate_bias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

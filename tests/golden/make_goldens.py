@@ -229,7 +229,50 @@ GAIN = 0.5
 SPEECH_CB = 1.0
 RIR_CB = 1.0
 
+def g7_location():
+    """LocationModule (vq_vae/location_model/location_model.py) at a small size (all tensors) and at the script's size
+    (scripts/train_location.py:23-24,41: 201 x 1024 -> 1; slices + checksums, fc_1 alone is 843 MB)."""
+    from acoustic_locating_vq_vae.vq_vae.location_model.location_model import LocationModule
+    from oracle import location_oracle as LO
+    out = {}
+    for tag, (L, K, od, B) in (("small", (5, 8, 3, 4)), ("full", (201, 1024, 1, 16))):
+        gain = 1.0 if tag == "small" else 12.0
+        p = LO.closed_form_location_params(LO.location_param_shapes(L, K, od), gain)
+        m = LocationModule(L, K, od)
+        m.load_state_dict(p)
+        idx = LO.hashed_indices(B, L, K, 31)
+        if tag == "small":
+            idx[1] = idx[0]                                  # two samples hitting the same columns: the scatter-add case
+        theta = torch.from_numpy(O.hashed_uniform(B, 32, 3.0))
+        loc = m(LO.onehot_codes(idx, K))
+        loss = LO.location_loss(loc, theta if od == 1 else theta.view(B, 1).expand(B, od))
+        loss.backward()
+        out[tag + ":cfg"] = np.array([L, K, od, B])
+        out[tag + ":gain"] = np.float64(gain)
+        out[tag + ":location"] = loc.detach().numpy()
+        out[tag + ":loss"] = np.float64(loss.item())
+        for k, v in m.named_parameters():
+            if tag == "small" and v.grad.numel() <= 50000:
+                out[tag + ":grad:" + k] = v.grad.numpy()
+            else:
+                out[tag + ":grad_slice:" + k] = sl(v.grad, 256 if k == "fc_1.weight" else 64)
+                out[tag + ":grad_sum:" + k] = checksum(v.grad)
+        if tag == "full":
+            # fc_1.weight.grad is zero except in the B*L touched columns: store those exactly (one row of the weight)
+            g1 = m.fc_1.weight.grad
+            cols = (np.arange(L)[None, :] * K + idx).reshape(-1)
+            out["full:fc1_grad_row7_touched"] = g1[7, torch.from_numpy(cols)].numpy()
+            out["full:fc1_grad_nonzero_cols"] = np.int64(int((g1.abs().sum(dim=0) != 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "g7_location.npz"), **out)
+    print("g7_location", {k: getattr(v, "shape", None) for k, v in out.items() if "grad" not in k})
+
+
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1:                      # e.g. `make_goldens.py g7_location`: regenerate a single fixture
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_tiny()
     g2_vq()
     big("speech", (201, 1024, 128, 3, 1024, 0.25, 1024), (2, 201, 500), False, None, True, SPEECH_CB)
@@ -237,3 +280,4 @@ if __name__ == "__main__":
     g3_echoed()
     g5_jitter()
     g6_stft()
+    g7_location()

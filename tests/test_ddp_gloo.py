@@ -133,3 +133,95 @@ def test_flat_buffers_views_and_shard():
     with pytest.raises(ValueError):
         shard_batch(x, 0, 3)
     assert fb.sync_grads() == 1.0                    # no process group: identity
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Trainer.step's collective pattern (north_star: "a single RCCL all-reduce of gradients ... per step").  The HIP
+# kernels cannot run here, so a stand-in model with the product's attribute layout (_encoder / _pre_vq_conv / _vq /
+# _decoder) computes in plain torch, and the optimiser launch is replaced; everything between -- bucket layout, the
+# two-part backward, sync calls, their order -- is the product's own Trainer code.
+class _TinyVQVAE(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._encoder = torch.nn.Linear(6, 5)
+        self._pre_vq_conv = torch.nn.Linear(5, 4)
+        self._vq = torch.nn.Linear(4, 4, bias=False)
+        self._decoder = torch.nn.Linear(4, 6)
+
+    def forward(self, x):
+        from acoustic_locating_vq_vae import _ops
+        z = self._pre_vq_conv(torch.relu(self._encoder(x)))
+        if _ops._LATENT_TAP is not None and z.requires_grad:
+            z = _ops.tap_latent(z)
+        q = self._vq(z)
+        return (q - z.detach()).square().mean(), self._decoder(q), torch.zeros(())
+
+
+def _trainer_worker(rank, world, port, ret, buckets):
+    _setup_paths()
+    import acoustic_locating_vq_vae.train_step as TS
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("ALVQ_GRAD_BUCKETS", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.numel())
+        return real(t, *a, **k)
+
+    dist.all_reduce = counting
+
+    class CpuTrainer(TS.Trainer):
+        def preprocess(self, raw, wiener=None):
+            return raw, raw
+
+        def forward_loss(self, x, target):
+            vq_loss, recon, perp = self.model(x)
+            err = F.mse_loss(recon, target)
+            return err + vq_loss, err, perp
+
+    class SGD:                                            # stands in for the one-launch flat Adam
+        def __init__(self, b):
+            self.b, self.step_count = b, 0
+
+        def prepare(self, grad_scale=1.0):
+            self.scale = grad_scale
+
+        def apply(self, skip=()):
+            with torch.no_grad():
+                self.b.flat.add_(self.b.grad, alpha=-0.05 * self.scale)
+
+    torch.manual_seed(3 + rank)                           # different init per rank: the broadcast must fix it
+    model = _TinyVQVAE()
+    tr = CpuTrainer(model, "speech", grad_buckets=buckets)
+    tr.opt = SGD(tr.buffers)
+    xg = torch.randn(8, 6, generator=torch.Generator().manual_seed(11))
+    per_step = []
+    for _ in range(3):
+        n0 = len(calls)
+        tr.step(TS.shard_batch(xg, rank, world))
+        per_step.append(len(calls) - n0)
+    gathered = [torch.zeros_like(tr.buffers.flat) for _ in range(world)]
+    dist.all_gather(gathered, tr.buffers.flat)
+    if rank == 0:
+        ret["per_step"] = per_step
+        ret["sizes"] = calls[-per_step[-1]:]
+        ret["total"] = tr.buffers.grad.numel()
+        ret["same"] = all(torch.equal(gathered[0], g) for g in gathered)
+        ret["bucketed"] = tr._buckets is not None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("buckets,expect", [(None, 1), (1, 1), (2, 2)])
+def test_trainer_step_all_reduce_calls(buckets, expect):
+    """Default (and grad_buckets=1): exactly ONE all-reduce of the whole flat buffer per Trainer.step.  grad_buckets=2:
+    two calls whose spans partition the buffer.  Ranks end every step with identical parameters either way."""
+    ret = mp.Manager().dict()
+    mp.spawn(_trainer_worker, args=(2, _free_port(), ret, buckets), nprocs=2, join=True)
+    assert ret["per_step"] == [expect] * 3, ret["per_step"]
+    assert sum(ret["sizes"]) == ret["total"], "every gradient element is reduced exactly once"
+    assert ret["bucketed"] == (expect == 2)
+    assert ret["same"]

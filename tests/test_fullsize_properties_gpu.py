@@ -146,6 +146,31 @@ def test_vq_idempotence_optimality_checksum_fullsize():
     assert float(enc.sum()) == idx.numel() and torch.equal(enc.argmax(dim=1), idx)
 
 
+def test_vq_stress_config_fullsize():
+    """BASELINE configs[3]: codebook 4096 x 256, batch 512 x L 500 => N = 256 000 rows, one GPU.  Indices bit-exact
+    against the CPU oracle's distance arithmetic on a strided sample of rows (every 499th: 514 rows spread over the
+    whole range, ~2 s of CPU work), int64 in range everywhere, idempotence on the code vectors, and the histogram /
+    perplexity as a checksum over all rows."""
+    Nr, K, D = 256000, 4096, 256
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(Nr, D, device="cuda", generator=g)
+    E = torch.randn(K, D, device="cuda", generator=g)
+    idx = N.vq_argmin(x, E)
+    assert idx.dtype == torch.int64 and idx.shape == (Nr,) and int(idx.min()) >= 0 and int(idx.max()) < K
+    rows = torch.arange(0, Nr, 499, device="cuda")
+    want = O.vq_distances(x[rows].cpu(), E.cpu()).argmin(dim=1)
+    assert torch.equal(idx[rows].cpu(), want)
+    # first and last row blocks too (edge tiles of the grid)
+    for lo in (0, Nr - 256):
+        assert torch.equal(idx[lo:lo + 256].cpu(), O.vq_distances(x[lo:lo + 256].cpu(), E.cpu()).argmin(dim=1))
+    q = E[idx[:65536]].contiguous()
+    assert torch.equal(N.vq_argmin(q, E), idx[:65536])                      # idempotence
+    _, out = N.vq_gather_loss(x, E, idx, 0.25)
+    p = torch.bincount(idx, minlength=K).double() / Nr
+    perp = float(torch.exp(-(p * torch.log(p + 1e-10)).sum()))
+    assert abs(float(out[1]) - perp) <= 1e-4 * perp
+
+
 # ------------------------------------------------------------------------------------------------- elementwise pieces
 def test_jitter_standardise_adam_fullsize():
     x = rnd(B, 128, L, seed=23)

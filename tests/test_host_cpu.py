@@ -115,8 +115,8 @@ def test_echoed_model_surface():
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src/acoustic_locating_vq_vae"),
                     reason="overlay check needs the reference checkout (build container only)")
 def test_overlay_resolves_non_hot_path_modules_from_the_reference():
-    """With the reference LATER on sys.path, hot-path modules come from this build and everything else
-    (location model, dataset, ...) keeps resolving from the reference: the scripts' imports all succeed."""
+    """With the reference LATER on sys.path, every module this build provides (hot path, dataset side, location head)
+    comes from this build and everything else (visualization, ...) keeps resolving from the reference."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -126,12 +126,16 @@ def test_overlay_resolves_non_hot_path_modules_from_the_reference():
         "import acoustic_locating_vq_vae.vq_vae.location_model.location_model as b;"
         "import acoustic_locating_vq_vae.rir_dataset_generator.specsdataset as c;"
         "from src.acoustic_locating_vq_vae.vq_vae.modules.residual import Residual;"
-        "print(a.__file__); print(b.__file__); print(c.__file__); print(Residual.__module__)"
+        "import importlib.util as u;"
+        "print(a.__file__); print(b.__file__); print(c.__file__); print(Residual.__module__);"
+        "print(u.find_spec('acoustic_locating_vq_vae.visualization').origin)"
     )
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
                PYTHONPATH=os.pathsep.join([pkg, os.path.join(pkg, "src"), "/root/reference", "/root/reference/src"]))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
-    # hot-path modules and the dataset side come from this build, the location head from the reference
-    assert lines[0].startswith(pkg) and lines[1].startswith("/root/reference") and lines[2].startswith(pkg)
+    # hot-path modules, the dataset side and the location head (rank 4) come from this build; a module
+    # this build does not provide (plotting) is found in the reference checkout
+    assert lines[0].startswith(pkg) and lines[1].startswith(pkg) and lines[2].startswith(pkg)
+    assert lines[4].startswith("/root/reference")

@@ -310,6 +310,51 @@ def test_graph_replay_equals_eager_steps():
     assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-5
 
 
+def test_graph_replay_survives_workspace_growth():
+    """A captured graph records the raw pointer of the scratch its weight-gradient / quantiser launches used.  A later
+    eager call that needs MORE scratch (a bigger batch, another model, another dtype -- bench.py does all three) must
+    not hand that memory back to the allocator: replay afterwards has to give the same steps as an undisturbed run."""
+    from acoustic_locating_vq_vae import _native as N
+    from acoustic_locating_vq_vae.train_step import Trainer
+    cfg = (20, 48, 8, 2, 24, 0.25, 64)
+    raws = [torch.randn(4, 20, 40, generator=torch.Generator().manual_seed(s)).cuda() for s in range(5)]
+    finals = []
+    for disturb in (False, True):
+        torch.manual_seed(7)
+        m = build(cfg)
+        with torch.no_grad():
+            m._vq._embedding.weight.normal_(0, 0.7)
+        m.train()
+        tr = Trainer(m, "speech")
+        np.random.seed(42)
+        tr.capture(raws[0], warmup=2)
+        if disturb:
+            # far larger split-K partials than the captured net; no jitter, so the np.random stream the captured
+            # trainer's jitter draws from is left alone
+            big = build((64, 256, 16, 2, 128, 0.25, 128), use_jitter=False).train()
+            xb = torch.randn(8, 64, 300).cuda()
+            loss, recon, _ = big(xb)
+            (loss + recon.square().mean()).backward()
+            junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]   # whatever was freed gets reused
+            torch.cuda.synchronize()
+            del junk
+        losses = [float(tr.step(r)[0]) for r in raws[1:]]
+        finals.append((losses, tr.buffers.flat.clone()))
+    assert np.all(np.isfinite(finals[1][0]))
+    assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1])
+    # the mechanism itself: a workspace that is outgrown is retired, never released, and scratch is per stream
+    dev = torch.device("cuda", torch.cuda.current_device())
+    small = N._workspace(1 << 20, dev)
+    ptr, n_retired = small.data_ptr(), len(N._WS_RETIRED)
+    large = N._workspace(small.numel() + (64 << 20), dev)
+    assert large.data_ptr() != ptr and len(N._WS_RETIRED) == n_retired + 1 and N._WS_RETIRED[-1].data_ptr() == ptr
+    assert N._workspace(1 << 20, dev).data_ptr() == large.data_ptr()          # grow-only
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert N._workspace(1 << 20, dev).data_ptr() != large.data_ptr()      # another stream, another buffer
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_two_part_backward_equals_single_backward(dtype):
     """The trainers' default (backward cut at the encoder output so the first gradient bucket's all-reduce can
