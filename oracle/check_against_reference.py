@@ -3,7 +3,8 @@
 TEST INFRASTRUCTURE.  Imports the reference read-only from /root/reference
 (PYTHONPATH must hold both /root/reference and /root/reference/src -- SURVEY 8c)
 and checks that ``oracle.vqvae_oracle`` reproduces it: outputs, indices, every
-parameter gradient, one Adam step, jitter index stream, echoed model.
+parameter gradient, one Adam step, jitter index stream, echoed model, and ``oracle.location_oracle``
+against the real LocationModule.
 
 Run:  cd /tmp && PYTHONDONTWRITEBYTECODE=1 \
       PYTHONPATH=/root/repo:/root/reference:/root/reference/src \
@@ -140,6 +141,36 @@ def check_adam():
     return d < 1e-7
 
 
+def check_location():
+    """oracle.location_oracle vs the real LocationModule (location_model.py:5-29) and the script's loss
+    (train_location.py:77-78, including its (B,) vs (B,1) broadcast)."""
+    from acoustic_locating_vq_vae.vq_vae.location_model.location_model import LocationModule
+    from oracle import location_oracle as LO
+    ok = True
+    for L, K, od, B in ((5, 8, 3, 4), (13, 32, 1, 6)):
+        torch.manual_seed(11)
+        m = LocationModule(L, K, od)
+        assert list(m.state_dict()) == list(LO.location_param_shapes(L, K, od)), "state_dict keys / order"
+        assert all(tuple(v.shape) == LO.location_param_shapes(L, K, od)[k] for k, v in m.state_dict().items())
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        idx = LO.hashed_indices(B, L, K, 5)
+        x = LO.onehot_codes(idx, K)
+        theta = torch.from_numpy(O.hashed_uniform(B, 6, 3.0))
+        tgt = theta if od == 1 else theta.view(B, 1).expand(B, od)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = m(x)
+            F.mse_loss(ref, tgt / torch.pi, reduction="mean").backward()
+            got = LO.location_forward(x, p)
+            LO.location_loss(got, tgt).backward()
+        d = maxdiff(ref, got)
+        gd = max(maxdiff(q.grad, p[k].grad) for k, q in m.named_parameters())
+        print("location L=%d K=%d out=%d: forward diff %.1e, grad diff %.1e" % (L, K, od, d, gd))
+        ok &= d == 0.0 and gd < 1e-7
+    return ok
+
+
 def main():
     ok = True
     ok &= check_vqvae((7, 16, 4, 2, 8, 0.25, 16), (2, 7, 13), True, 0)
@@ -150,6 +181,7 @@ def main():
     ok &= check_jitter()
     ok &= check_echoed()
     ok &= check_adam()
+    ok &= check_location()
     print("ALL OK" if ok else "SOME FAILED")
     sys.exit(0 if ok else 1)
 

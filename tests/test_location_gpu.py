@@ -1,0 +1,150 @@
+"""Location head on the GPU: LocationModule with fc_1 as an embedding-bag gather, against
+oracle.location_oracle (pinned by the real module, oracle/check_against_reference.py) and the golden made by the real
+reference (tests/golden/g7_location.npz).  The gather is exact fp32 up to summation order; the bar is 1e-3 and the
+measured differences are ~1e-6."""
+import io
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from acoustic_locating_vq_vae import _native as N  # noqa: E402
+from oracle import location_oracle as LO  # noqa: E402
+from oracle import vqvae_oracle as O  # noqa: E402
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def sl(t, n=64):
+    f = t.detach().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].cpu().numpy()
+
+
+def module(L, K, od, p):
+    from acoustic_locating_vq_vae.vq_vae.location_model.location_model import LocationModule
+    m = LocationModule(L, K, od)
+    m.load_state_dict(p)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("B,L,K,M", [(1, 1, 1, 1), (4, 5, 8, 7), (3, 201, 64, 130), (16, 201, 1024, 64), (7, 13, 33, 257)])
+def test_embedding_bag_kernels_match_dense_product(B, L, K, M):
+    torch.manual_seed(B * 1000 + L)
+    W = torch.randn(M, L * K) / L ** 0.5
+    bias = torch.randn(M)
+    idx = torch.from_numpy(LO.hashed_indices(B, L, K, 3))
+    if B > 1:
+        idx[1] = idx[0]                                           # the same columns from two samples
+    x = LO.onehot_codes(idx, K).flatten(1)
+    want = x @ W.t() + bias
+    got = N.embedding_bag_fwd(W.cuda(), bias.cuda(), idx.int().cuda(), L, K)
+    assert rel(got, want) < 1e-5
+    dz = torch.randn(B, M)
+    dW, db = N.embedding_bag_bwd(dz.cuda(), idx.int().cuda(), L, K)
+    assert rel(dW, dz.t() @ x) < 1e-5 and rel(db, dz.sum(0)) < 1e-5
+    # one-hot detection: exact rows pass, any deviation raises the flag
+    i2, flag = N.onehot_to_index(LO.onehot_codes(idx, K).view(-1, K).cuda())
+    assert int(flag.item()) == 0 and torch.equal(i2.cpu().long().view(B, L), idx)
+    if K > 1:
+        bad = LO.onehot_codes(idx, K).view(-1, K).clone()
+        bad[0, (int(idx[0, 0]) + 1) % K] = 1.0                    # two ones in a row
+        assert int(N.onehot_to_index(bad.cuda())[1].item()) != 0
+        bad = LO.onehot_codes(idx, K).view(-1, K) * 0.5           # a single non-unit entry
+        assert int(N.onehot_to_index(bad.cuda())[1].item()) != 0
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_location_module_against_reference_golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "g7_location.npz"))
+    L, K, od, B = (int(v) for v in g[tag + ":cfg"])
+    p = LO.closed_form_location_params(LO.location_param_shapes(L, K, od), float(g[tag + ":gain"]))
+    m = module(L, K, od, p).train()
+    idx = LO.hashed_indices(B, L, K, 31)
+    if tag == "small":
+        idx[1] = idx[0]
+    theta = torch.from_numpy(O.hashed_uniform(B, 32, 3.0))
+    tgt = theta if od == 1 else theta.view(B, 1).expand(B, od)
+    for form in ("onehot", "indices"):
+        m.zero_grad()
+        x = LO.onehot_codes(idx, K).cuda() if form == "onehot" else torch.from_numpy(idx).cuda()
+        loc = m(x)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss = LO.location_loss(loc, tgt.cuda())              # train_location.py:77-78
+        loss.backward()
+        assert rel(loc, g[tag + ":location"]) < 1e-4, form
+        assert abs(float(loss) - float(g[tag + ":loss"])) < 1e-4 * abs(float(g[tag + ":loss"])), form
+        for k, v in m.named_parameters():
+            if tag + ":grad:" + k in g.files:
+                assert rel(v.grad, g[tag + ":grad:" + k]) < 1e-3, (form, k)
+            else:
+                want = g[tag + ":grad_slice:" + k]
+                n = 256 if k == "fc_1.weight" else 64
+                assert np.abs(want).max() == 0 and float(sl(v.grad, n).__abs__().max()) == 0 or rel(sl(v.grad, n), want) < 1e-3, (form, k)
+        if tag == "full":
+            cols = torch.from_numpy((np.arange(L)[None, :] * K + idx).reshape(-1)).cuda()
+            g1 = m.fc_1.weight.grad
+            assert rel(g1[7, cols], g["full:fc1_grad_row7_touched"]) < 1e-3
+            assert int((g1.abs().sum(dim=0) != 0).sum()) == int(g["full:fc1_grad_nonzero_cols"])   # nothing but the touched columns
+
+
+def test_location_module_general_input_and_surface():
+    """A float input that is not one-hot takes the dense product and matches the oracle; state_dict keys, whole-module
+    pickles and CPU tensors behave as everywhere else in the package."""
+    L, K, od, B = 6, 16, 2, 5
+    p = LO.closed_form_location_params(LO.location_param_shapes(L, K, od))
+    m = module(L, K, od, p)
+    assert list(m.state_dict()) == list(LO.location_param_shapes(L, K, od))
+    x = torch.rand(B, L, K)
+    assert rel(m(x.cuda()), LO.location_forward(x, p)) < 1e-4
+    xg = LO.onehot_codes(LO.hashed_indices(B, L, K, 2), K).cuda().requires_grad_(True)   # wants d/dx: dense path
+    m(xg).sum().backward()
+    assert xg.grad is not None and xg.grad.shape == (B, L, K)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    idx = torch.from_numpy(LO.hashed_indices(B, L, K, 4)).cuda()
+    assert torch.equal(m2(idx), m(idx))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(B, L, K))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(B, L + 1, dtype=torch.int64).cuda())
+
+
+def test_location_training_loop_tracks_oracle():
+    """The script's loop body (train_location.py:69-82: one-hot codes -> location -> mse(theta/pi) -> Adam) on the module
+    API with torch.optim.Adam, against the same loop on the CPU oracle."""
+    L, K, od, B = 21, 32, 1, 8
+    p = LO.closed_form_location_params(LO.location_param_shapes(L, K, od), gain=3.0)
+    m = module(L, K, od, p).train()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt_o = torch.optim.Adam(list(po.values()), lr=1e-3)
+    for step in range(4):
+        idx = LO.hashed_indices(B, L, K, 40 + step)
+        theta = torch.from_numpy(O.hashed_uniform(B, 50 + step, 3.0))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt_o.zero_grad()
+            want = LO.location_loss(LO.location_forward(LO.onehot_codes(idx, K), po), theta)
+            want.backward()
+            opt_o.step()
+            opt.zero_grad()
+            got = LO.location_loss(m(LO.onehot_codes(idx, K).cuda()), theta.cuda())
+            got.backward()
+            opt.step()
+        assert abs(float(got) - float(want)) < 1e-4 * abs(float(want)) + 1e-7, (step, float(got), float(want))
+    # Adam divides by sqrt(v): where a gradient is at rounding level its update is +-lr regardless of magnitude, so the
+    # parameters agree to a few lr/|w| (measured 1.5e-4), not to the 1e-6 of the losses above
+    for k, v in m.named_parameters():
+        assert rel(v, po[k]) < 1e-3, k

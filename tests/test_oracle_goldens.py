@@ -156,3 +156,35 @@ def test_g3_default_configs(golden_dir, tag):
     assert rel(sl(out["recon"]), g["recon_slice"]) < 1e-4
     for key in p:
         assert rel(sl(p[key].grad), g["grad_slice:" + key]) < 1e-4, key
+
+
+def test_g7_location_oracle_reproduces_reference(golden_dir):
+    """oracle.location_oracle vs the golden made by the real LocationModule: small config in full, the script's
+    201 x 1024 config through outputs, loss, gradient slices / checksums and the touched columns of fc_1's gradient."""
+    import warnings
+    from oracle import location_oracle as LO
+    g = load(golden_dir, "g7_location.npz")
+    for tag in ("small", "full"):
+        L, K, od, B = (int(v) for v in g[tag + ":cfg"])
+        p = {k: v.requires_grad_(True) for k, v in
+             LO.closed_form_location_params(LO.location_param_shapes(L, K, od), float(g[tag + ":gain"])).items()}
+        idx = LO.hashed_indices(B, L, K, 31)
+        if tag == "small":
+            idx[1] = idx[0]
+        theta = torch.from_numpy(O.hashed_uniform(B, 32, 3.0))
+        loc = LO.location_forward(LO.onehot_codes(idx, K), p)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                 # the script's (B,) vs (B,1) target broadcast, kept on purpose
+            loss = LO.location_loss(loc, theta if od == 1 else theta.view(B, 1).expand(B, od))
+        loss.backward()
+        assert rel(loc, g[tag + ":location"]) < 1e-6 and abs(float(loss) - float(g[tag + ":loss"])) < 1e-6 * abs(float(g[tag + ":loss"]))
+        for k, v in p.items():
+            if tag + ":grad:" + k in g.files:
+                assert rel(v.grad, g[tag + ":grad:" + k]) < 1e-5, k
+            else:
+                n = 256 if k == "fc_1.weight" else 64
+                assert rel(sl(v.grad, n), g[tag + ":grad_slice:" + k]) < 1e-5 or np.abs(g[tag + ":grad_slice:" + k]).max() == 0, k
+        if tag == "full":
+            cols = torch.from_numpy((np.arange(L)[None, :] * K + idx).reshape(-1))
+            assert rel(p["fc_1.weight"].grad[7, cols], g["full:fc1_grad_row7_touched"]) < 1e-5
+            assert int((p["fc_1.weight"].grad.abs().sum(dim=0) != 0).sum()) == int(g["full:fc1_grad_nonzero_cols"])
