@@ -1,0 +1,523 @@
+// f16mx convolution (see f16mx_common.h for the format): forward / data-gradient / ConvTranspose of the wide and narrow
+// layers alike, plus the boundary conversions of the format.
+//
+// Tiling and staging are those of conv1d_bf16x3.hip -- 256 out-channels x 256 rows per workgroup, 8 waves, a wave owns
+// 128 x 64; K-tile = (32 channels, one tap) = four 16 KB slabs (W.H, W.Q, X.H, X.Q) in one of two LDS stages filled by
+// LDS-DMA -- but the wave's block is 4 x 2 tiles of 32x32 and a K-tile is TWO phases of 512 matrix-pipe cycles:
+//   phase 1  fp16 main term : 2 k-steps x 8 v_mfma_f32_32x32x16_f16          | meanwhile: the Q fragments of this K-tile
+//            s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier    <- K-tile t+1 landed; every read of this stage is done
+//   phase 2  fp8 cross terms: 8 v_mfma_scale_f32_32x32x64_f8f6f4              | meanwhile: DMA of K-tile t+2 into THIS
+//                                                                               stage, H fragments of K-tile t+1
+// 96 fragment VGPRs + 128 accumulators, the barrier between phases whose operands are in registers, as in bf16x3.
+#include <stdlib.h>
+
+#include "alvq_common.h"
+#include "f16mx_common.h"
+
+namespace alvq {
+
+constexpr int FX_M = 256, FX_R = 256, FX_K = 32;
+constexpr int FX_SLAB = FX_M * FX_K * 2;          // 16384 B
+constexpr int FX_STAGE = 4 * FX_SLAB;             // W.H, W.Q, X.H, X.Q
+constexpr int FX_LDS = 2 * FX_STAGE;              // 131072 B
+constexpr int FX_CS = FX_M + 4;
+static_assert(64 * FX_CS * 4 <= FX_LDS, "C slab must fit");
+
+struct ConvFxArgs {
+  ConvBArgs b;                        // H planes (and everything shared); mask_bits / bits_out unused
+  long x_plane, wp_plane, y_plane;    // element (u16) offsets from an H plane to its Q plane
+  int ea, eb;                         // E8M0 scale exponents: weights (A operand), activations / gradients (B operand and outputs)
+  const float* out_scale;             // OUT == 1: device scalar multiplied into the fp32 output (undoes a loss scale), or null
+  int dbg;                            // ablation switches of the DBG instantiation (ALVQ_FX_DBG): 1 no in-loop DMA, 2 no in-loop
+                                      // fragment reads, 4 no wait + barrier, 8 no epilogue -- timing experiments only
+};
+
+// 16 consecutive channels of one row, reconstructed from an f16mx tensor: += H + lo8 * S_lo
+__device__ __forceinline__ void fx_load_add16(const u16* p, long plane, long row_elems, int c, float s_lo, float (&v)[16]) {
+  const u32x4 h0 = *(const u32x4*)(p + row_elems + c), h1 = *(const u32x4*)(p + row_elems + c + 8);
+  const u32x4 ql = *(const u32x4*)((const unsigned char*)(p + plane) + row_elems * 2 + fx_q_off(c) + 32);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a0, a1, b0, b1;
+    fx_join2(h0[e], ql[e >> 1], (e & 1) * 2, s_lo, a0, a1);
+    fx_join2(h1[e], ql[2 + (e >> 1)], (e & 1) * 2, s_lo, b0, b1);
+    v[2 * e] += a0;
+    v[2 * e + 1] += a1;
+    v[8 + 2 * e] += b0;
+    v[8 + 2 * e + 1] += b1;
+  }
+}
+
+__device__ __forceinline__ void fx_store16(u16* p, long plane, long row_elems, int c, float inv_s, float inv_s_lo, const float (&v)[16]) {
+  unsigned h[8], qh[4], ql[4];
+  fx_split<16>(v, inv_s, inv_s_lo, h, qh, ql);
+  *(u32x4*)(p + row_elems + c) = u32x4{h[0], h[1], h[2], h[3]};
+  *(u32x4*)(p + row_elems + c + 8) = u32x4{h[4], h[5], h[6], h[7]};
+  unsigned char* q = (unsigned char*)(p + plane) + row_elems * 2 + fx_q_off(c);
+  *(u32x4*)q = u32x4{qh[0], qh[1], qh[2], qh[3]};
+  *(u32x4*)(q + 32) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+}
+
+// Register-direct epilogue of one wave's 128 (m) x 64 (rows) block held as 4 x 2 accumulators of 32x32.  Lane (j = lane &
+// 31, h = lane >> 5) holds, of row j of tile (mi, ni), the channels (q & 3) + 8 (q >> 2) + 4 h in register q: four groups
+// of four.  Two rounds of v_permlane32_swap (groups 0 <-> 2, then 1 <-> 3) give the lane 16 CONSECUTIVE channels
+// (16 h .. 16 h + 15 of the tile), so every load and store is 16 bytes and the two lanes of a row cover one whole 64-byte
+// H segment and one whole 64-byte Q chunk.
+__device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32x16 (&acc)[4][2], int m0, int r0, int lane, int wm0,
+                                                 int wn0) {
+  const ConvBArgs& a = ax.b;
+  const int j = lane & 31, h = lane >> 5;
+  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  const float s_lo = fx_pow2(ax.eb - FX_LO_SHIFT), inv_s = fx_pow2(254 - ax.eb), inv_s_lo = fx_pow2(254 - ax.eb + FX_LO_SHIFT);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int row = r0 + wn0 + ni * 32 + j;
+    int b, l;
+    const bool ok = row_valid(row, Lp1, ndata, &b, &l);
+    const long ro = (long)row * a.Mop;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      if (m0 + wm0 + mi * 32 >= a.Mop) continue;        // Mop % 64 == 0: a 32-channel tile is inside or outside as a whole
+      const int cb = m0 + wm0 + mi * 32 + 16 * h;
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const u32x2 ra = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][e]), __float_as_uint(acc[mi][ni][8 + e]), false, false);
+        const u32x2 rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][4 + e]), __float_as_uint(acc[mi][ni][12 + e]), false, false);
+        v[e] = __uint_as_float(ra[0]);
+        v[4 + e] = __uint_as_float(ra[1]);
+        v[8 + e] = __uint_as_float(rb[0]);
+        v[12 + e] = __uint_as_float(rb[1]);
+      }
+      if (!ok) {                                         // gap / tail rows stay zero in both planes
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.f;
+        fx_store16(a.y, ax.y_plane, ro, cb, inv_s, inv_s_lo, v);
+        if (a.y2) fx_store16(a.y2, ax.y_plane, ro, cb, inv_s, inv_s_lo, v);
+        continue;
+      }
+      if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += (cb + e < a.M) ? a.bias[cb + e] : 0.f;
+      }
+      if (a.skip1) fx_load_add16(a.skip1, ax.y_plane, ro, cb, s_lo, v);
+      if (a.skip2) fx_load_add16(a.skip2, ax.y_plane, ro, cb, s_lo, v);
+      if (a.relu & 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (a.mask) {   // the sign of a split value is the sign of its H plane (fp16 reaches 6e-8; smaller activations are zero)
+        const u32x4 s0 = *(const u32x4*)(a.mask + ro + cb), s1 = *(const u32x4*)(a.mask + ro + cb + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = fx_h2f_lo(s0[e]) > 0.f ? v[2 * e] : 0.f;
+          v[2 * e + 1] = fx_h2f_hi(s0[e]) > 0.f ? v[2 * e + 1] : 0.f;
+          v[8 + 2 * e] = fx_h2f_lo(s1[e]) > 0.f ? v[8 + 2 * e] : 0.f;
+          v[8 + 2 * e + 1] = fx_h2f_hi(s1[e]) > 0.f ? v[8 + 2 * e + 1] : 0.f;
+        }
+      }
+      fx_store16(a.y, ax.y_plane, ro, cb, inv_s, inv_s_lo, v);
+      if (a.y2) {
+        fx_load_add16(a.post, ax.y_plane, ro, cb, s_lo, v);
+        fx_store16(a.y2, ax.y_plane, ro, cb, inv_s, inv_s_lo, v);
+      }
+    }
+  }
+}
+
+template <int OUT, bool DBG = false>
+__global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax, int KW) {
+  const int dbg = DBG ? ax.dbg : 0;
+  const ConvBArgs& a = ax.b;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int PAD = (KW - 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
+  const int m0 = (tile % a.mtiles) * FX_M;
+  const int r0 = (tile / a.mtiles) * FX_R;
+  const int Cp = a.Cp;
+
+  // ---- DMA: identical to the bf16x3 kernel (a piece is 16 rows x 64 B; lane i -> row i>>2, slot i&3 <- 16-byte group
+  // (i&3) ^ h[(row>>2)&3] of the row's 64-byte chunk); plane 0 = H, plane 1 = Q
+  const int hsel = (lane >> 4) & 3;
+  const int hval = (hsel == 0) ? 0 : (4 - hsel);
+  const int srow = lane >> 2, sgrp = (lane & 3) ^ hval;
+  const unsigned lane_off = (unsigned)(srow * Cp + sgrp * 8) * 2u;
+  const long tap_w = (long)a.Mp128 * Cp * 2;
+  const long row16 = (long)Cp * 32;
+  const long wpl = ax.wp_plane * 2, xpl = ax.x_plane * 2;
+  const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) unsigned char*)lds);
+  auto dma = [&](const char* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+  };
+  const char* const wb = (const char*)(a.wp + ((long)m0 + wave * 32) * Cp);
+  const char* const xb = (const char*)(a.x + ((long)r0 - PAD + wave * 32) * Cp);
+  int is_chunk = 0, is_tap = 0;
+  auto issue = [&](int stage) {
+    const unsigned dst = lds0 + stage * FX_STAGE + wave * 2048;
+    const char* ws = wb + is_tap * tap_w + is_chunk * (FX_K * 2);
+    const char* xs = xb + (long)is_tap * Cp * 2 + is_chunk * (FX_K * 2);
+    dma(ws, dst);
+    dma(ws + row16, dst + 1024);
+    dma(ws + wpl, dst + FX_SLAB);
+    dma(ws + wpl + row16, dst + FX_SLAB + 1024);
+    dma(xs, dst + 2 * FX_SLAB);
+    dma(xs + row16, dst + 2 * FX_SLAB + 1024);
+    dma(xs + xpl, dst + 3 * FX_SLAB);
+    dma(xs + xpl + row16, dst + 3 * FX_SLAB + 1024);
+    if (++is_tap == KW) {
+      is_tap = 0;
+      ++is_chunk;
+    }
+  };
+
+  // ---- fragment reads for the 32x32 shapes: lane (r = lane & 31, g = lane >> 5) takes the 16-byte groups g and 2 + g of
+  // row r of a 32-row block.  H slab: group g = k-step 0 (channels 8g..8g+7), group 2+g = k-step 1.  Q slab: group g =
+  // hi8[16g..16g+15], group 2+g = lo8[16g..16g+15]; the A operand wants (hi8, lo8), the B operand (lo8, hi8), so that
+  // block 0 of the scaled MFMA pairs A.hi8 with B.lo8 and block 1 A.lo8 with B.hi8.  The slot swizzle of the staging
+  // (slot = group ^ {0,3,2,1}[(row>>2)&3]) makes each of these reads conflict-free for this lane pattern too.
+  const int r32 = lane & 31, g = lane >> 5;
+  const int hq = (r32 >> 2) & 3, hsw = hq == 0 ? 0 : 4 - hq;
+  const int off0 = r32 * 64 + ((g ^ hsw) << 4), off1 = r32 * 64 + (((2 + g) ^ hsw) << 4);
+  const unsigned char* const abase = lds + wm0 * 64;
+  const unsigned char* const bbase = lds + 2 * FX_SLAB + wn0 * 64;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  f16x8_t aH[4][2], bH[2][2];
+  i32x8 aQ[4], bQ[2];
+#define FX_RDH_A(STAGE, MI, KS) aH[MI][KS] = *(const f16x8_t*)(abase + (STAGE) * FX_STAGE + (MI) * 2048 + ((KS) ? off1 : off0));
+#define FX_RDH_B(STAGE, NI, KS) bH[NI][KS] = *(const f16x8_t*)(bbase + (STAGE) * FX_STAGE + (NI) * 2048 + ((KS) ? off1 : off0));
+#define FX_RDQ(DST, P, FIRST, SECOND)                                                           \
+  {                                                                                             \
+    const i32x4 q0_ = *(const i32x4*)((P) + (FIRST)), q1_ = *(const i32x4*)((P) + (SECOND));    \
+    DST = __builtin_shufflevector(q0_, q1_, 0, 1, 2, 3, 4, 5, 6, 7);                            \
+  }
+#define FX_RDQ_A(STAGE, MI) FX_RDQ(aQ[MI], abase + (STAGE) * FX_STAGE + FX_SLAB + (MI) * 2048, off0, off1)
+#define FX_RDQ_B(STAGE, NI) FX_RDQ(bQ[NI], bbase + (STAGE) * FX_STAGE + FX_SLAB + (NI) * 2048, off1, off0)
+
+  // block scales of the fp8 MFMA: lanes 0-31 supply block 0, lanes 32-63 block 1.  Opaque to the compiler so that it keeps
+  // them in registers instead of re-materialising them by VALU moves in front of the inline-asm MFMAs (no hazard padding
+  // happens for instructions it cannot see).
+  int sa = g ? ax.ea - FX_LO_SHIFT : ax.ea, sb = g ? ax.eb : ax.eb - FX_LO_SHIFT;
+  asm volatile("" : "+v"(sa), "+v"(sb));
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
+#define FX_MMH(KS)                                                                                                       \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                      \
+      asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(aH[mi][KS]), "v"(bH[ni][KS]));
+#define FX_MMQ(MI0)                                                                                                      \
+  _Pragma("unroll") for (int mi = (MI0); mi < (MI0) + 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)          \
+      asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"                                   \
+          : "+v"(acc[mi][ni]) : "v"(aQ[mi]), "v"(bQ[ni]), "v"(sa), "v"(sb));
+#define FX_SB __builtin_amdgcn_sched_barrier(0);
+
+  const int n = (Cp / FX_K) * KW;   // K-tiles; even (Cp % 64 == 0)
+  const bool early = wave < 4;
+
+  issue(0);
+  issue(1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) { FX_RDH_A(0, mi, 0) FX_RDH_A(0, mi, 1) }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) { FX_RDH_B(0, ni, 0) FX_RDH_B(0, ni, 1) }
+
+#define FX_TILE(S, MORE)                                                                                                 \
+  FX_MMH(0) FX_SB                                                                                                        \
+  if (!(dbg & 2)) { FX_RDQ_B(S, 0) FX_RDQ_B(S, 1) FX_RDQ_A(S, 0) FX_RDQ_A(S, 1) FX_RDQ_A(S, 2) FX_RDQ_A(S, 3) } FX_SB    \
+  FX_MMH(1) FX_SB                                                                                                        \
+  if (!(dbg & 4)) {                                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
+    __builtin_amdgcn_s_barrier();                                                                                        \
+  }                                                                                                                      \
+  if (early && (MORE) && !(dbg & 1)) issue(S);                                                                           \
+  FX_MMQ(0) FX_SB                                                                                                        \
+  if (!(dbg & 2)) {                                                                                                      \
+    FX_RDH_B((S) ^ 1, 0, 0) FX_RDH_B((S) ^ 1, 1, 0) FX_RDH_A((S) ^ 1, 0, 0) FX_RDH_A((S) ^ 1, 1, 0)                       \
+    FX_RDH_A((S) ^ 1, 2, 0) FX_RDH_A((S) ^ 1, 3, 0)                                                                      \
+  }                                                                                                                      \
+  FX_SB                                                                                                                  \
+  if (!early && (MORE) && !(dbg & 1)) issue(S);                                                                          \
+  FX_MMQ(2) FX_SB                                                                                                        \
+  if (!(dbg & 2)) {                                                                                                      \
+    FX_RDH_B((S) ^ 1, 0, 1) FX_RDH_B((S) ^ 1, 1, 1) FX_RDH_A((S) ^ 1, 0, 1) FX_RDH_A((S) ^ 1, 1, 1)                       \
+    FX_RDH_A((S) ^ 1, 2, 1) FX_RDH_A((S) ^ 1, 3, 1)                                                                      \
+  }                                                                                                                      \
+  FX_SB
+
+  for (int t = 0; t < n; t += 2) {
+    FX_TILE(0, t + 2 < n)
+    FX_TILE(1, t + 3 < n)
+  }
+#undef FX_TILE
+#undef FX_SB
+#undef FX_MMQ
+#undef FX_MMH
+#undef FX_RDQ_B
+#undef FX_RDQ_A
+#undef FX_RDQ
+#undef FX_RDH_B
+#undef FX_RDH_A
+  // the compiler's hazard recogniser does not see inside the asm MFMAs: cover the MFMA-result -> VALU-read wait states
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+  if (dbg & 8) {
+    if (acc[0][0][0] == 12345.678f) a.y[0] = 1;   // keep the accumulators alive
+    return;
+  }
+  if (OUT == 0) {
+    wave_epilogue_fx(ax, acc, m0, r0, lane, wm0, wn0);
+    return;
+  }
+  __syncthreads();   // the C slab overlays the stages: the trailing fragment reads of every wave must be done
+  // ---- OUT == 1 (fp32 NCL, bias only, optional output scale): four 64-row slabs through an fp32 LDS tile
+  float* Cs = (float*)lds;
+  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  const float oscale = ax.out_scale ? *ax.out_scale : 1.f;
+  for (int slab = 0; slab < 4; ++slab) {
+    if ((wave & 3) == slab) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int rl = ni * 32 + r32, ml = wm0 + mi * 32 + 8 * q4 + 4 * g;
+            *(f32x4*)(Cs + rl * FX_CS + ml) =
+                f32x4{acc[mi][ni][4 * q4], acc[mi][ni][4 * q4 + 1], acc[mi][ni][4 * q4 + 2], acc[mi][ni][4 * q4 + 3]};
+          }
+    }
+    __syncthreads();
+    {
+      const int rl = tid & 63, row = r0 + slab * 64 + rl;
+      int b, l;
+      if (row_valid(row, Lp1, ndata, &b, &l)) {
+        for (int ml = tid >> 6; ml < FX_M; ml += 8) {
+          const int m = m0 + ml;
+          if (m >= a.M) break;
+          a.y_ncl[((long)b * a.M + m) * a.L + l] = (Cs[rl * FX_CS + ml] + (a.bias ? a.bias[m] : 0.f)) * oscale;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ boundary conversions
+// (B,C,L) fp32 -> f16mx NLC planes, optionally multiplied by a device scalar (the loss scale of a backward chain)
+__global__ __launch_bounds__(256) void ncl_to_nlc_fx_kernel(const float* x, u16* y, long plane, int B, int C, int L, int Cp,
+                                                            int rows_total, int e, const float* scale) {
+  __shared__ float tile[32][33];
+  const int ct = Cp / 32;
+  const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int Lp1 = L + 1, ndata = B * Lp1;
+  const float sc = scale ? *scale : 1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, row = r0 + tx;
+    int b, l;
+    const bool ok = row_valid(row, Lp1, ndata, &b, &l) && c < C;
+    tile[ty + 8 * i][tx] = ok ? x[((long)b * C + c) * L + l] * sc : 0.f;
+  }
+  __syncthreads();
+  // thread (row = tid >> 3, 4 channels at (tid & 7) * 4): 8 bytes of H, 4 of hi8, 4 of lo8
+  const int rr = threadIdx.x >> 3, cq = (threadIdx.x & 7) * 4;
+  const int row = r0 + rr;
+  if (row < rows_total) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = tile[cq + k][rr];
+    unsigned h[2], qh[1], ql[1];
+    fx_split<4>(v, fx_pow2(254 - e), fx_pow2(254 - e + FX_LO_SHIFT), h, qh, ql);
+    *(u32x2*)(y + (long)row * Cp + c0 + cq) = u32x2{h[0], h[1]};
+    unsigned char* q = (unsigned char*)(y + plane) + (long)row * Cp * 2 + fx_q_off(c0) + cq;
+    *(unsigned*)q = qh[0];
+    *(unsigned*)(q + 32) = ql[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void nlc_to_ncl_fx_kernel(const u16* x, long plane, float* y, int B, int C, int L, int Cp,
+                                                            int rows_total, int e, const float* scale) {
+  __shared__ float tile[32][33];
+  const int ct = Cp / 32;
+  const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int Lp1 = L + 1, ndata = B * Lp1;
+  const float sc = scale ? *scale : 1.f, s_lo = fx_pow2(e - FX_LO_SHIFT);
+  const int rr = threadIdx.x >> 3, cq = (threadIdx.x & 7) * 4;
+  const int rowq = r0 + rr;
+  if (rowq < rows_total) {
+    const u32x2 h = *(const u32x2*)(x + (long)rowq * Cp + c0 + cq);
+    const unsigned ql = *(const unsigned*)((const unsigned char*)(x + plane) + (long)rowq * Cp * 2 + fx_q_off(c0) + cq + 32);
+    float v0, v1, v2, v3;
+    fx_join2(h[0], ql, 0, s_lo, v0, v1);
+    fx_join2(h[1], ql, 2, s_lo, v2, v3);
+    tile[rr][cq] = v0 * sc;
+    tile[rr][cq + 1] = v1 * sc;
+    tile[rr][cq + 2] = v2 * sc;
+    tile[rr][cq + 3] = v3 * sc;
+  } else {
+    tile[rr][cq] = tile[rr][cq + 1] = tile[rr][cq + 2] = tile[rr][cq + 3] = 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, row = r0 + tx;
+    int b, l;
+    if (row_valid(row, Lp1, ndata, &b, &l) && c < C) y[((long)b * C + c) * L + l] = tile[tx][ty + 8 * i];
+  }
+}
+
+// out = t > 0 ? dy : 0 on all three parts (16 channels per thread step; the sign of a value is the sign of its H part)
+__global__ __launch_bounds__(256) void relu_mask_fx_kernel(const u16* dy, const u16* t, u16* out, long plane, int rows, int Cp) {
+  const long n16 = (long)rows * Cp / 16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+    const long row = (i * 16) / Cp;
+    const int c = (int)((i * 16) % Cp);
+    const long ro = row * Cp;
+    const u32x4 m0 = *(const u32x4*)(t + ro + c), m1 = *(const u32x4*)(t + ro + c + 8);
+    u32x4 h0 = *(const u32x4*)(dy + ro + c), h1 = *(const u32x4*)(dy + ro + c + 8);
+    const unsigned char* qs = (const unsigned char*)(dy + plane) + ro * 2 + fx_q_off(c);
+    u32x4 qh = *(const u32x4*)qs, ql = *(const u32x4*)(qs + 32);
+    unsigned keep = 0;   // bit k: channel c + k survives
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      keep |= (fx_h2f_lo(m0[e]) > 0.f ? 1u : 0u) << (2 * e) | (fx_h2f_hi(m0[e]) > 0.f ? 1u : 0u) << (2 * e + 1);
+      keep |= (fx_h2f_lo(m1[e]) > 0.f ? 1u : 0u) << (8 + 2 * e) | (fx_h2f_hi(m1[e]) > 0.f ? 1u : 0u) << (9 + 2 * e);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned k0 = (keep >> (2 * e)) & 3u, k1 = (keep >> (8 + 2 * e)) & 3u;
+      h0[e] &= ((k0 & 1u) ? 0xffffu : 0u) | ((k0 & 2u) ? 0xffff0000u : 0u);
+      h1[e] &= ((k1 & 1u) ? 0xffffu : 0u) | ((k1 & 2u) ? 0xffff0000u : 0u);
+      const unsigned kb = (keep >> (4 * e)) & 15u;
+      const unsigned bm = ((kb & 1u) ? 0xffu : 0u) | ((kb & 2u) ? 0xff00u : 0u) | ((kb & 4u) ? 0xff0000u : 0u) | ((kb & 8u) ? 0xff000000u : 0u);
+      qh[e] &= bm;
+      ql[e] &= bm;
+    }
+    *(u32x4*)(out + ro + c) = h0;
+    *(u32x4*)(out + ro + c + 8) = h1;
+    unsigned char* qd = (unsigned char*)(out + plane) + ro * 2 + fx_q_off(c);
+    *(u32x4*)qd = qh;
+    *(u32x4*)(qd + 32) = ql;
+  }
+}
+
+// Loss scale of a backward chain, chosen on the device: state = {S, 1/S, amax bits, -}.  Pass 1 folds |x| into state[2]
+// (integer max of the float bits: order-independent, exact); pass 2 turns it into the power of two that puts amax at
+// 2^8 -- 2^8 of headroom below fp16's 65504 for growth along the chain, 2^22 above its smallest normal -- and rearms.
+__global__ __launch_bounds__(256) void grad_amax_kernel(const float* x, long n, float* state) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)state + 2, __float_as_uint(m));
+}
+__global__ void grad_scale_kernel(float* state) {
+  const unsigned bits = ((unsigned*)state)[2];
+  const float amax = __uint_as_float(bits);
+  int e = 127;                                        // S = 1 when the gradient is all zero / not finite
+  if (amax > 0.f && amax < 3.0e38f) {
+    const int ea = (int)((bits >> 23) & 0xff);        // amax in [2^(ea-127), 2^(ea-126))
+    e = 127 + 8 - (ea - 127) - 1;                     // S * amax in [2^7, 2^8)
+    e = e < 1 ? 1 : (e > 253 ? 253 : e);
+  }
+  state[0] = fx_pow2(e);
+  state[1] = fx_pow2(254 - e);
+  ((unsigned*)state)[2] = 0u;
+}
+
+}  // namespace alvq
+
+using namespace alvq;
+
+static inline int pad_to(int x, int q) { return (x + q - 1) / q * q; }
+static inline long nlc_plane_elems(int B, int L, int C) {
+  return ((long)alvq_nlc_rows(B, L) + 2L * alvq_nlc_guard_rows()) * pad_to(C, 64);
+}
+
+extern "C" int alvq_ncl_to_nlc_f16mx(const float* x, void* y, int B, int C, int L, const float* scale, void* stream) {
+  ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_ncl_to_nlc_f16mx: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_ncl_to_nlc_f16mx: bad dims");
+  const int Cp = pad_to(C, 64), rows = (int)alvq_nlc_rows(B, L);
+  hipLaunchKernelGGL(ncl_to_nlc_fx_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y,
+                     nlc_plane_elems(B, L, C), B, C, L, Cp, rows, FX_E_ACT, scale);
+  return check_launch("alvq_ncl_to_nlc_f16mx");
+}
+
+extern "C" int alvq_nlc_to_ncl_f16mx(const void* x, float* y, int B, int C, int L, const float* scale, void* stream) {
+  ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_nlc_to_ncl_f16mx: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_nlc_to_ncl_f16mx: bad dims");
+  const int Cp = pad_to(C, 64), rows = (int)alvq_nlc_rows(B, L);
+  hipLaunchKernelGGL(nlc_to_ncl_fx_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, (const u16*)x,
+                     nlc_plane_elems(B, L, C), y, B, C, L, Cp, rows, FX_E_ACT, scale);
+  return check_launch("alvq_nlc_to_ncl_f16mx");
+}
+
+extern "C" int alvq_relu_mask_f16mx(const void* dy, const void* t, void* out, int B, int C, int L, void* stream) {
+  ALVQ_REQUIRE(dy && t && out, ALVQ_EINVAL, "alvq_relu_mask_f16mx: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_relu_mask_f16mx: bad dims");
+  const int Cp = pad_to(C, 64), rows = (int)alvq_nlc_rows(B, L);
+  long gq = ((long)rows * Cp / 16 + 255) / 256;
+  if (gq > 2048) gq = 2048;
+  hipLaunchKernelGGL(relu_mask_fx_kernel, dim3((int)gq), dim3(256), 0, (hipStream_t)stream, (const u16*)dy, (const u16*)t, (u16*)out,
+                     nlc_plane_elems(B, L, C), rows, Cp);
+  return check_launch("alvq_relu_mask_f16mx");
+}
+
+extern "C" int alvq_grad_scale_f32(const float* x, int64_t n, float* state, void* stream) {
+  ALVQ_REQUIRE(x && state, ALVQ_EINVAL, "alvq_grad_scale_f32: null pointer");
+  ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_grad_scale_f32: n <= 0");
+  long gq = (n + 256 * 8 - 1) / (256 * 8);
+  if (gq > 1024) gq = 1024;
+  hipLaunchKernelGGL(grad_amax_kernel, dim3((int)gq), dim3(256), 0, (hipStream_t)stream, x, (long)n, state);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  return check_launch("alvq_grad_scale_f32");
+}
+
+extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
+                                 const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M, int L,
+                                 int KW, int relu, const float* out_scale, void* stream) {
+  ALVQ_REQUIRE(x && wp && (y || y_ncl), ALVQ_EINVAL, "alvq_conv1d_f16mx: null x/wp/y");
+  ALVQ_REQUIRE(!(y && y_ncl), ALVQ_EINVAL, "alvq_conv1d_f16mx: choose one of y (NLC) and y_ncl (NCL fp32)");
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_f16mx: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_f16mx: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE((y2 == nullptr) == (post == nullptr), ALVQ_EINVAL, "alvq_conv1d_f16mx: y2 and post go together");
+  ALVQ_REQUIRE(!y_ncl || (!skip1 && !skip2 && !mask && !post && !relu), ALVQ_EUNSUPPORTED,
+               "alvq_conv1d_f16mx: the NCL fp32 epilogue fuses bias (and the output scale) only");
+  ALVQ_REQUIRE((long)B * (L + 1) < (1L << 30), ALVQ_EUNSUPPORTED, "alvq_conv1d_f16mx: problem too large");
+  const long rows = alvq_nlc_rows(B, L);
+  ConvFxArgs a{{(const u16*)x, (const u16*)wp, bias, (const u16*)skip1, (const u16*)skip2, (const u16*)mask, (const u16*)post,
+                (u16*)y, (u16*)y2, y_ncl, B, L, pad_to(C, 64), M, pad_to(M, 64), pad_to(M, WP_ROWS), relu ? 1 : 0,
+                (int)(rows / FX_R), pad_to(M, FX_M) / FX_M},
+               nlc_plane_elems(B, L, C), (long)alvq_packed_weight_elems(M, C, KW), nlc_plane_elems(B, L, M),
+               FX_E_W, FX_E_ACT, out_scale, 0};
+  static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
+  a.dbg = dbg_env;
+  hipStream_t s = (hipStream_t)stream;
+  static DeviceOnce attr;
+  if (attr.need()) {
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+  }
+  const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
+  if (dbg_env && y) {
+    hipLaunchKernelGGL((conv1d_f16mx_kernel<0, true>), grid, block, FX_LDS, s, a, KW);
+    return check_launch("alvq_conv1d_f16mx(dbg)");
+  }
+  if (y) hipLaunchKernelGGL((conv1d_f16mx_kernel<0>), grid, block, FX_LDS, s, a, KW);
+  else hipLaunchKernelGGL((conv1d_f16mx_kernel<1>), grid, block, FX_LDS, s, a, KW);
+  return check_launch("alvq_conv1d_f16mx");
+}

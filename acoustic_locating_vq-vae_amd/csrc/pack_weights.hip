@@ -5,6 +5,7 @@
 // runs of one m; IOK: (m, tap) runs of one c), turns the tile through LDS and writes 16-byte runs along c.
 #include "alvq_common.h"
 #include "bf16_common.h"
+#include "f16mx_common.h"
 
 namespace alvq {
 
@@ -17,7 +18,7 @@ struct PackDesc {
 struct PackBatch {
   PackDesc d[PB_MAX];
   int n;
-  long plane[PB_MAX];   // PLANES == 2: element offset of the lo image
+  long plane[PB_MAX];   // PLANES >= 2: element offset of the second image (bf16x3: lo; f16mx: Q)
 };
 
 template <int PLANES>
@@ -52,6 +53,15 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackBatch b) {
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[t][mr][cg + e];
+    if (PLANES == 3) {   // f16mx: H image (fp16) + Q image ([hi8 x 32 | lo8 x 32] per 32 channels), weight-class scale
+      unsigned h[4], qh[2], ql[2];
+      fx_split<8>(v, fx_pow2(254 - FX_E_W), fx_pow2(254 - FX_E_W + FX_LO_SHIFT), h, qh, ql);
+      *(u32x4*)(d.wp + o) = u32x4{h[0], h[1], h[2], h[3]};
+      unsigned char* q = (unsigned char*)(d.wp + b.plane[di]) + ((long)t * d.Mp + m0 + mr) * d.Cp * 2 + fx_q_off(c0 + cg);
+      *(u32x2*)q = u32x2{qh[0], qh[1]};
+      *(u32x2*)(q + 32) = u32x2{ql[0], ql[1]};
+      continue;
+    }
     u32x4 hi;
 #pragma unroll
     for (int e = 0; e < 4; ++e) hi[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
@@ -76,7 +86,7 @@ static inline int pad_to(int x, int q) { return (x + q - 1) / q * q; }
 
 extern "C" int alvq_pack_weights_bf16_batch(const alvq_pack_desc* descs, int n, int planes, void* stream) {
   ALVQ_REQUIRE(descs && n > 0, ALVQ_EINVAL, "alvq_pack_weights_bf16_batch: no descriptors");
-  ALVQ_REQUIRE(planes == 1 || planes == 2, ALVQ_EINVAL, "alvq_pack_weights_bf16_batch: planes=%d (1 or 2)", planes);
+  ALVQ_REQUIRE(planes >= 1 && planes <= 3, ALVQ_EINVAL, "alvq_pack_weights_bf16_batch: planes=%d (1, 2 or 3)", planes);
   for (int i = 0; i < n; ++i) {
     const alvq_pack_desc& s = descs[i];
     ALVQ_REQUIRE(s.w && s.wp, ALVQ_EINVAL, "alvq_pack_weights_bf16_batch: null pointer in descriptor %d", i);
@@ -97,7 +107,8 @@ extern "C" int alvq_pack_weights_bf16_batch(const alvq_pack_desc* descs, int n, 
       blocks += (d.Mp / 32) * d.ctiles;
     }
     if (planes == 1) hipLaunchKernelGGL(pack_weights_batch_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
-    else hipLaunchKernelGGL(pack_weights_batch_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    else if (planes == 2) hipLaunchKernelGGL(pack_weights_batch_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(pack_weights_batch_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     int rc = check_launch("alvq_pack_weights_bf16_batch");
     if (rc) return rc;
   }

@@ -77,6 +77,13 @@ _SIGNATURES = {
     "alvq_conv1d_bf16x3": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p]),
     "alvq_conv1d_wgrad_bf16x3_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_bf16x3": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
+    "alvq_grad_scale_f32": (_i32, [_c_void_p, _i64, _c_void_p, _c_void_p]),
+    "alvq_ncl_to_nlc_f16mx": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p]),
+    "alvq_nlc_to_ncl_f16mx": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p]),
+    "alvq_relu_mask_f16mx": (_i32, [_c_void_p] * 3 + [_i32, _i32, _i32, _c_void_p]),
+    "alvq_conv1d_f16mx": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p, _c_void_p]),
+    "alvq_conv1d_wgrad_f16mx_workspace_bytes": (_i64, [_i32] * 5),
+    "alvq_conv1d_wgrad_f16mx": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p, _c_void_p]),
     "alvq_onehot_to_index_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
     "alvq_embedding_bag_fwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 4 + [_c_void_p]),
     "alvq_embedding_bag_bwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 5 + [_c_void_p]),
@@ -486,15 +493,22 @@ def spec_rir_wiener(speech_spec, echoed_spec):
 
 # ----------------------------------------------------------------------------------------------- bf16 path
 class NLC:
-    """A bf16 activation in the NLC-padded layout (see include/alvq.h): storage = guard rows + matrix + guard rows."""
-    __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard", "planes", "has_bits")
+    """An activation in the NLC-padded layout (see include/alvq.h): storage = guard rows + matrix + guard rows.
 
-    def __init__(self, B, L, C, device, planes=1):
+    ``fmt``: "bf16" (one plane), "bf16x3" (hi + lo bf16 planes) or "f16mx" (fp16 H plane + fp8 Q plane; same bytes and
+    geometry as bf16x3).  ``gscale``: for a gradient in the f16mx format, the 4-float device state of its loss scale
+    ({S, 1/S, ...}, alvq_grad_scale_f32) -- inherited by everything computed from it and divided out where the chain
+    leaves the format; None for forward tensors."""
+    __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard", "planes", "has_bits", "fmt", "gscale")
+
+    def __init__(self, B, L, C, device, planes=1, fmt=None, gscale=None):
         """planes=2: the split-bf16 form (hi plane, then the lo plane at +alvq_nlc_plane_bytes).
         planes=1 buffers carry a tail of rows*Cp/8 bytes for the sign bits a ReLU'd convolution can leave behind
         (see alvq_conv1d_bf16); ``has_bits`` says whether they are valid."""
         L_ = lib()
         self.B, self.L, self.C, self.planes = B, L, C, planes
+        self.fmt = fmt or ("bf16x3" if planes == 2 else "bf16")
+        self.gscale = gscale
         self.Cp = L_.alvq_nlc_channels(C)
         self.rows = L_.alvq_nlc_rows(B, L)
         self.guard = L_.alvq_nlc_guard_rows()
@@ -503,10 +517,12 @@ class NLC:
         self.storage = torch.empty((n,), device=device, dtype=torch.bfloat16)
 
     @classmethod
-    def wrap(cls, storage, B, L, C, planes=1, has_bits=False):
+    def wrap(cls, storage, B, L, C, planes=1, has_bits=False, fmt=None):
         self = cls.__new__(cls)
         L_ = lib()
         self.B, self.L, self.C, self.planes = B, L, C, planes
+        self.fmt = fmt or ("bf16x3" if planes == 2 else "bf16")
+        self.gscale = None
         self.Cp, self.rows, self.guard = L_.alvq_nlc_channels(C), L_.alvq_nlc_rows(B, L), L_.alvq_nlc_guard_rows()
         self.storage = storage
         self.has_bits = bool(has_bits) and storage.numel() >= (self.rows + 2 * self.guard) * self.Cp + self.rows * self.Cp // 16
@@ -527,6 +543,8 @@ class NLC:
 
     def to_ncl(self):
         """(B,C,L) fp32 copy -- test/debug helper (torch indexing, not on the hot path)."""
+        if self.fmt == "f16mx":
+            return nlc_to_ncl(self)
         m = self.matrix(0).float()
         if self.planes == 2:
             m = m + self.matrix(1).float()
@@ -535,22 +553,39 @@ class NLC:
 
 
 def nlc_like(ref, C):
-    return NLC(ref.B, ref.L, C, ref.storage.device, ref.planes)
+    return NLC(ref.B, ref.L, C, ref.storage.device, ref.planes, ref.fmt, ref.gscale)
+
+
+def _sptr(gscale, which):
+    """Device pointer to S (which = 0) or 1/S (which = 1) of a loss-scale state, or None."""
+    return None if gscale is None else gscale.data_ptr() + 4 * which
+
+
+def grad_scale(x):
+    """Loss scale of a backward chain in the f16mx format: 4-float device state {S, 1/S, -, -} with S the power of two
+    that puts amax|x| in [2^7, 2^8) -- chosen on the device, no host round trip (graph-capturable)."""
+    state = torch.empty((4,), device=x.device, dtype=torch.float32)
+    fill_(state, 0.0)
+    _check(lib().alvq_grad_scale_f32(_ptr(x, name="x"), x.numel(), state.data_ptr(), _stream()), "alvq_grad_scale_f32")
+    return state
 
 
 def _nlc_ptr(t, ref, C, name):
     if t is None:
         return None
-    if not isinstance(t, NLC) or (t.B, t.L, t.C, t.planes) != (ref.B, ref.L, C, ref.planes):
-        raise RuntimeError("%s: expected an NLC activation of (B=%d, L=%d, C=%d, planes=%d)" % (name, ref.B, ref.L, C, ref.planes))
+    if not isinstance(t, NLC) or (t.B, t.L, t.C, t.planes, t.fmt) != (ref.B, ref.L, C, ref.planes, ref.fmt):
+        raise RuntimeError("%s: expected an NLC activation of (B=%d, L=%d, C=%d, %s)" % (name, ref.B, ref.L, C, ref.fmt))
     return t.ptr
 
 
-def ncl_to_nlc(x, planes=1):
-    """(B,C,L) fp32 dense -> NLC bf16 (planes=2: split hi/lo)."""
+def ncl_to_nlc(x, planes=1, fmt=None, gscale=None):
+    """(B,C,L) fp32 dense -> NLC bf16 (planes=2: split hi/lo; fmt="f16mx": fp16 + fp8 planes, multiplied by the loss
+    scale S of ``gscale`` when given)."""
     B, C, L = x.shape
-    out = NLC(B, L, C, x.device, planes)
-    if planes == 2:
+    out = NLC(B, L, C, x.device, planes, fmt, gscale)
+    if out.fmt == "f16mx":
+        _check(lib().alvq_ncl_to_nlc_f16mx(_ptr(x, name="x"), out.ptr, B, C, L, _sptr(gscale, 0), _stream()), "alvq_ncl_to_nlc_f16mx")
+    elif planes == 2:
         _check(lib().alvq_ncl_to_nlc_bf16x3(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16x3")
     else:
         _check(lib().alvq_ncl_to_nlc_bf16(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16")
@@ -560,7 +595,9 @@ def ncl_to_nlc(x, planes=1):
 def nlc_to_ncl(a):
     """NLC bf16 -> (B,C,L) fp32 dense."""
     y = torch.empty((a.B, a.C, a.L), device=a.storage.device, dtype=torch.float32)
-    if a.planes == 2:
+    if a.fmt == "f16mx":
+        _check(lib().alvq_nlc_to_ncl_f16mx(a.ptr, _ptr(y), a.B, a.C, a.L, _sptr(a.gscale, 1), _stream()), "alvq_nlc_to_ncl_f16mx")
+    elif a.planes == 2:
         _check(lib().alvq_nlc_to_ncl_bf16x3(a.ptr, _ptr(y), a.B, a.C, a.L, _stream()), "alvq_nlc_to_ncl_bf16x3")
     else:
         _check(lib().alvq_nlc_to_ncl_f32(a.ptr, _ptr(y), a.B, a.C, a.L, _stream()), "alvq_nlc_to_ncl_f32")
@@ -574,8 +611,10 @@ def pack_weight(w, w_layout, planes=1):
     else:
         C, M, KW = w.shape
     n = lib().alvq_packed_weight_elems(M, C, KW)
-    wp = torch.empty((planes * n,), device=w.device, dtype=torch.bfloat16)
-    if planes == 2:
+    wp = torch.empty((min(planes, 2) * n,), device=w.device, dtype=torch.bfloat16)
+    if planes == 3:                                  # f16mx: H + Q images
+        pack_weights_batch([(w, wp, w_layout)], 3)
+    elif planes == 2:
         _check(lib().alvq_pack_weight_bf16x3(_ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout, _stream()), "alvq_pack_weight_bf16x3")
     else:
         _check(lib().alvq_pack_weight_bf16(_ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout, _stream()), "alvq_pack_weight_bf16")
@@ -595,7 +634,7 @@ def packed_weight_alloc(w, w_layout, planes=1):
     else:
         C, M, KW = w.shape
     n = lib().alvq_packed_weight_elems(M, C, KW)
-    return torch.empty((planes * n,), device=w.device, dtype=torch.bfloat16), (M, C, KW, planes)
+    return torch.empty((min(planes, 2) * n,), device=w.device, dtype=torch.bfloat16), (M, C, KW, planes)
 
 
 def pack_weights_batch(entries, planes=1):
@@ -608,7 +647,7 @@ def pack_weights_batch(entries, planes=1):
             M, C, KW = w.shape
         else:
             C, M, KW = w.shape
-        need = planes * lib().alvq_packed_weight_elems(M, C, KW)
+        need = min(planes, 2) * lib().alvq_packed_weight_elems(M, C, KW)
         if wp.numel() != need or wp.dtype != torch.bfloat16:
             raise RuntimeError("pack_weights_batch: packed image has %d elements, expected %d" % (wp.numel(), need))
         d.w, d.wp, d.M, d.C, d.KW, d.w_layout = _ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout
@@ -618,7 +657,10 @@ def pack_weights_batch(entries, planes=1):
 
 def relu_mask_bf16(dy, t):
     out = nlc_like(dy, dy.C)
-    if dy.planes == 2:
+    if dy.fmt == "f16mx":
+        _check(lib().alvq_relu_mask_f16mx(dy.ptr, _nlc_ptr(t, dy, dy.C, "t"), out.ptr, dy.B, dy.C, dy.L, _stream()),
+               "alvq_relu_mask_f16mx")
+    elif dy.planes == 2:
         _check(lib().alvq_relu_mask_bf16x3(dy.ptr, _nlc_ptr(t, dy, dy.C, "t"), out.ptr, dy.B, dy.C, dy.L, _stream()),
                "alvq_relu_mask_bf16x3")
     else:
@@ -635,8 +677,8 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     wp, (M, C, KW, wplanes) = packed
     if C != x.C:
         raise RuntimeError("conv1d_bf16: weight expects %d input channels, x has %d" % (C, x.C))
-    if wplanes != x.planes:
-        raise RuntimeError("conv1d_bf16: weight packed with %d plane(s), activation has %d" % (wplanes, x.planes))
+    if wplanes != (3 if x.fmt == "f16mx" else x.planes):
+        raise RuntimeError("conv1d_bf16: weight packed for format %d, activation is %s" % (wplanes, x.fmt))
     split = x.planes == 2
     if bias is not None and bias.numel() != M:
         raise RuntimeError("conv1d_bf16: bias has %d elements, expected %d" % (bias.numel(), M))
@@ -647,7 +689,9 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
         y = nlc_like(x, M)
         y2 = nlc_like(x, M) if post is not None else None
     # same dispatch rule as alvq_conv1d_bf16: wide layers run the 256x256-tile kernel
-    if split:
+    if x.fmt == "f16mx":
+        family, fn = "conv1d_f16mx_kernel", lib().alvq_conv1d_f16mx
+    elif split:
         family, fn = "conv1d_bf16x3_kernel", lib().alvq_conv1d_bf16x3
     else:
         # mirrors the dispatch in csrc/conv1d_bf16.hip: wide layers go to the 256x256-tile kernels (k3 for width 3)
@@ -664,6 +708,8 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
             mask_bits, mask_ptr = mask.bits_ptr, None
         bits_out = y.bits_ptr if (y is not None and relu and USE_SIGN_BITS) else None
         extra = (mask_bits, bits_out)
+    elif x.fmt == "f16mx":
+        extra = (_sptr(x.gscale, 1) if out_ncl else None,)      # a gradient leaving the format: divide the loss scale out
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
         rc = fn(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),
                                     _nlc_ptr(skip2, x, M, "skip2"), mask_ptr,
@@ -690,9 +736,13 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
         raise RuntimeError("conv1d_wgrad_bf16: dw_out has shape %s, expected %s" % (tuple(dw_out.shape), shape))
     if want_bias and dbias_out is None:
         dbias_out = torch.empty((M,), device=dev, dtype=torch.float32)
-    if dy.planes != x.planes:
-        raise RuntimeError("conv1d_wgrad_bf16: dy and x differ in planes")
-    if x.planes == 2:
+    if (dy.planes, dy.fmt) != (x.planes, x.fmt):
+        raise RuntimeError("conv1d_wgrad_bf16: dy and x differ in format")
+    extra = ()
+    if x.fmt == "f16mx":
+        family, fn, wsfn = "conv1d_wgrad_f16mx_kernel", lib().alvq_conv1d_wgrad_f16mx, lib().alvq_conv1d_wgrad_f16mx_workspace_bytes
+        extra = (_sptr(dy.gscale, 1),)
+    elif x.planes == 2:
         family, fn, wsfn = "conv1d_wgrad_bf16x3_kernel", lib().alvq_conv1d_wgrad_bf16x3, lib().alvq_conv1d_wgrad_bf16x3_workspace_bytes
     else:
         family, fn, wsfn = "conv1d_wgrad_bf16_v2_kernel", lib().alvq_conv1d_wgrad_bf16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes
@@ -700,7 +750,7 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
         rc = fn(dy.ptr, x.ptr, _ptr(dw_out, name="dw"),
                                           _ptr(dbias_out, name="dbias") if want_bias else None, ws.data_ptr(),
-                                          x.B, C, M, x.L, KW, w_layout, int(bool(accumulate)), _stream())
+                                          x.B, C, M, x.L, KW, w_layout, int(bool(accumulate)), *extra, _stream())
     _check(rc, "alvq_conv1d_wgrad_bf16")
     return (dw_out, dbias_out) if want_bias else dw_out
 

@@ -16,7 +16,12 @@ Two precisions share these chains through a small "engine" object:
   evaluated as hi*hi + hi*lo + lo*hi: fp32-grade parity (~1e-5) at a third of the bf16 MFMA rate, i.e. several
   times the exact-fp32 MFMA that gfx950 offers (it has no TF32/xf32).
 
-Select with ``set_compute_dtype("f32" | "bf16" | "bf16x3")`` or the environment variable ``ALVQ_DTYPE``
+* ``f16mx`` -- the split pipeline at TWO matrix-pipe units per product: every tensor is an fp16 plane plus an fp8
+  (hi, lo) plane, products are fp16*fp16 (one fp16 MFMA) + hi8*lo8 + lo8*hi8 (one block-scaled fp8 MFMA at twice the
+  rate); ~1.5e-5 per product, same parity class as bf16x3 at ~2/3 of its matrix time.  Gradients run under a
+  power-of-two loss scale chosen on the device (csrc/f16mx_common.h).
+
+Select with ``set_compute_dtype("f32" | "bf16" | "bf16x3" | "f16mx")`` or the environment variable ``ALVQ_DTYPE``
 (default f32).
 """
 from __future__ import annotations
@@ -35,8 +40,8 @@ _DTYPE = os.environ.get("ALVQ_DTYPE", "f32")
 
 def set_compute_dtype(name):
     global _DTYPE
-    if name not in ("f32", "bf16", "bf16x3"):
-        raise ValueError("compute dtype must be 'f32', 'bf16' or 'bf16x3', got %r" % (name,))
+    if name not in ("f32", "bf16", "bf16x3", "f16mx"):
+        raise ValueError("compute dtype must be 'f32', 'bf16', 'bf16x3' or 'f16mx', got %r" % (name,))
     _DTYPE = name
 
 
@@ -204,7 +209,7 @@ def _need_gpu(x, who):
 class _F32Engine:
     name = "f32"
 
-    def enter(self, x):
+    def enter(self, x, grad=False):
         return dense(x)
 
     def leave(self, a):
@@ -229,23 +234,27 @@ class _F32Engine:
 
 class _BF16Engine:
     name = "bf16"
-    planes = 1
+    planes = 1          # planes of an activation
+    wplanes = 1         # format code of a packed weight (alvq_pack_weights_bf16_batch)
+    fmt = "bf16"
 
     def __init__(self):
         self._packed = {}
 
     def _w(self, w, layout):
         if _ACTIVE_POOL is not None:
-            hit = _ACTIVE_POOL.lookup(w, layout, self.planes)
+            hit = _ACTIVE_POOL.lookup(w, layout, self.wplanes)
             if hit is not None:
                 return hit
         key = (w.data_ptr(), layout)
         pk = self._packed.get(key)
         if pk is None:
-            pk = self._packed[key] = N.pack_weight(w.detach(), layout, self.planes)
+            pk = self._packed[key] = N.pack_weight(w.detach(), layout, self.wplanes)
         return pk
 
-    def enter(self, x):
+    def enter(self, x, grad=False):
+        """fp32 (B,C,L) -> the engine's layout.  ``grad``: x is a gradient entering a backward chain (only the f16mx
+        engine cares: it picks the chain's loss scale from x)."""
         return N.ncl_to_nlc(dense(x), self.planes)
 
     def leave(self, a):
@@ -267,7 +276,7 @@ class _BF16Engine:
         return N.conv1d_wgrad_bf16_multi if self.planes == 1 else None
 
     def pack(self, act):
-        return act.storage, (act.B, act.L, act.C, act.planes, act.has_bits)
+        return act.storage, (act.B, act.L, act.C, act.planes, act.has_bits, act.fmt)
 
     def unpack(self, tensor, meta):
         return N.NLC.wrap(tensor, *meta)
@@ -276,11 +285,30 @@ class _BF16Engine:
 class _BF16x3Engine(_BF16Engine):
     name = "bf16x3"
     planes = 2
+    wplanes = 2
+    fmt = "bf16x3"
+
+
+class _F16MXEngine(_BF16Engine):
+    name = "f16mx"
+    planes = 2
+    wplanes = 3
+    fmt = "f16mx"
+
+    def enter(self, x, grad=False):
+        x = dense(x)
+        return N.ncl_to_nlc(x, 2, "f16mx", N.grad_scale(x) if grad else None)
+
+    @property
+    def wgrad_multi(self):
+        return None
+
+
+_ENGINES = {"f32": _F32Engine, "bf16": _BF16Engine, "bf16x3": _BF16x3Engine, "f16mx": _F16MXEngine}
 
 
 def _engine(name=None):
-    name = name or _DTYPE
-    return _BF16x3Engine() if name == "bf16x3" else _BF16Engine() if name == "bf16" else _F32Engine()
+    return _ENGINES[name or _DTYPE]()
 
 
 def _save(ctx, eng, tensors, acts):
@@ -385,7 +413,7 @@ class EncoderFn(torch.autograd.Function):
         R = ctx.R
         eng, (wc, bc, w1, w2), acts = _load(ctx)
         xi, ts, us = acts[0], acts[1:R + 2], acts[R + 2:]
-        dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, eng.enter(d_out), xi, ts, us, wc, bc, w1, w2, R,
+        dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, eng.enter(d_out, grad=True), xi, ts, us, wc, bc, w1, w2, R,
                                                    ctx.needs_input_grad[0])
         return dx, dwc, dbc, dw1, dw2, None
 
@@ -408,7 +436,7 @@ class LatentFn(torch.autograd.Function):
         R = ctx.R
         eng, (wc, bc, w1, w2, wp, bp), acts = _load(ctx)
         xi, out, ts, us = acts[0], acts[1], acts[2:R + 3], acts[R + 3:]
-        dzi = eng.enter(dz)
+        dzi = eng.enter(dz, grad=True)
         d_out = eng.conv(dzi, wp, IOK)
         dwp, dbp = _wgrad(eng, dzi, out, 3, OIK, wp, bp)
         dx, dwc, dbc, dw1, dw2 = _encoder_backward(eng, d_out, xi, ts, us, wc, bc, w1, w2, R, ctx.needs_input_grad[0])
@@ -434,7 +462,7 @@ class StackFn(torch.autograd.Function):
         R = ctx.R
         eng, (w1, w2), acts = _load(ctx)
         ts, us = acts[:R + 1], acts[R + 1:]
-        dh = eng.relu_mask(eng.enter(d_out), ts[R])
+        dh = eng.relu_mask(eng.enter(d_out, grad=True), ts[R])
         dh0, dw1, dw2 = _stack_backward(eng, dh, ts, us, w1, w2, R)
         return eng.leave(dh0), dw1, dw2, None
 
@@ -454,7 +482,7 @@ class ResidualLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         eng, (w1, w2), (t, u) = _load(ctx)
-        dyi = eng.enter(dy)
+        dyi = eng.enter(dy, grad=True)
         du = eng.conv(dyi, w2, IOK, mask=u)
         dw2, _ = _wgrad(eng, dyi, u, 1, OIK, w2)
         dw1, _ = _wgrad(eng, du, t, 3, OIK, w1)
@@ -478,7 +506,7 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         eng, plain, (xi,) = _load(ctx)
         w, b = plain[0], (plain[1] if ctx.has_bias else None)
-        dyi = eng.enter(dy)
+        dyi = eng.enter(dy, grad=True)
         kw = w.shape[2]
         dw, db = _wgrad(eng, dyi, xi, kw, ctx.layout, w, b if ctx.needs_input_grad[2] else None)
         dx = eng.conv(dyi, w, IOK if ctx.layout == OIK else OIK, out_f32=True) if ctx.needs_input_grad[0] else None
@@ -523,7 +551,7 @@ class DecoderFn(torch.autograd.Function):
         R = ctx.R
         eng, (wd, w1, w2, wt1, wt2, wt3, bd, bt1, bt2, bt3), acts = _load(ctx)
         qj, a1, a2, ts, us = acts[0], acts[1], acts[2], acts[3:R + 4], acts[R + 4:]
-        dyi = eng.enter(dy)
+        dyi = eng.enter(dy, grad=True)
         da2 = eng.conv(dyi, wt3, OIK, mask=a2)                                   # convT data-grad, * (a2 > 0)
         dwt3, dbt3 = _wgrad(eng, dyi, a2, 3, IOK, wt3, bt3)
         da1 = eng.conv(da2, wt2, OIK, mask=a1)

@@ -209,7 +209,8 @@ int alvq_pack_weight_bf16(const float* w, void* wp, int M, int C, int KW, int w_
 /* The same for n weights in one launch (a train step re-packs every conv weight, in the forward and in the
  * data-gradient layout, after each optimiser update: one launch instead of ~20).  `descs` is a HOST array; it is
  * copied into the kernel argument, so the call can be captured into a hipGraph.  planes = 1: bf16 images;
- * planes = 2: the hi + lo images of the split-bf16 path (as alvq_pack_weight_bf16x3). */
+ * planes = 2: the hi + lo images of the split-bf16 path (as alvq_pack_weight_bf16x3); planes = 3: the H + Q images of
+ * the f16mx path (two images of alvq_packed_weight_elems 2-byte units each, weight-class scale). */
 typedef struct alvq_pack_desc {
   const float* w;   /* fp32 weight, (M,C,KW) for ALVQ_W_OIK or (C,M,KW) for ALVQ_W_IOK */
   void* wp;         /* packed image(s): planes * alvq_packed_weight_elems(M,C,KW) bf16 values */
@@ -269,6 +270,32 @@ int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bias, const v
 int64_t alvq_conv1d_wgrad_bf16x3_workspace_bytes(int B, int C, int M, int L, int KW);
 int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
                              int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
+
+/* ================================================================================================
+ * "f16mx" split path: fp32-grade results at TWO matrix-pipe units per product.  Every value v is H = fp16(v) plus
+ * hi8 = e4m3(v/S), lo8 = e4m3((v-H)/(S*2^-11)); a product is H*H (one fp16 MFMA) + hi8*lo8 + lo8*hi8 (one
+ * block-scaled fp8 MFMA at twice the fp16 rate per K), ~1.5e-5 rms per product.  S is a power of two per tensor class
+ * (activations and loss-scaled gradients 1, weights 2^-8; csrc/f16mx_common.h).  An NLC-padded operand is two planes of
+ * a bf16 plane's geometry: H as [rows][Cp] fp16, then at +alvq_nlc_plane_bytes(B,L,C) Q as [rows][Cp/32][hi8 x32|lo8 x32];
+ * packed weights likewise (alvq_pack_weights_bf16_batch with planes = 3).  Same contracts as the bf16x3 entry points of
+ * the same name, plus device scalars that carry a loss scale in and out of a backward chain:
+ *   alvq_grad_scale_f32    state[0] = S, state[1] = 1/S with S the power of two that puts amax|x| in [2^7, 2^8)
+ *                          (state: 4 floats, zero-initialised by the caller once; re-armed by every call)
+ *   alvq_ncl_to_nlc_f16mx  multiplies by *scale (NULL = 1) while converting; alvq_nlc_to_ncl_f16mx likewise on the way out
+ *   alvq_conv1d_f16mx      y_ncl output multiplied by *out_scale (NULL = 1)
+ *   alvq_conv1d_wgrad_f16mx  dw / dbias multiplied by *inv_scale (NULL = 1)
+ * ============================================================================================== */
+int alvq_grad_scale_f32(const float* x, int64_t n, float* state, void* stream);
+int alvq_ncl_to_nlc_f16mx(const float* x, void* y, int B, int C, int L, const float* scale, void* stream);
+int alvq_nlc_to_ncl_f16mx(const void* x, float* y, int B, int C, int L, const float* scale, void* stream);
+int alvq_relu_mask_f16mx(const void* dy, const void* t, void* out, int B, int C, int L, void* stream);
+int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
+                      const void* mask, const void* post, void* y, void* y2, float* y_ncl,
+                      int B, int C, int M, int L, int KW, int relu, const float* out_scale, void* stream);
+int64_t alvq_conv1d_wgrad_f16mx_workspace_bytes(int B, int C, int M, int L, int KW);
+int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
+                            int B, int C, int M, int L, int KW, int w_layout, int accumulate,
+                            const float* inv_scale, void* stream);
 
 /* ================================================================================================
  * Location head: LocationModule.fc_1 = nn.Linear(L*K, M) on the flattened one-hot codes of a

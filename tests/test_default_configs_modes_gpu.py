@@ -4,6 +4,7 @@ throughput mode (bf16 -- what bench.py's headline runs) and the split parity mod
 ceilings, every number is printed, and no assertion is conditional on another one passing.
 
 Measured on MI355X (B=2 goldens): bf16x3  z 6e-6, recon 7e-6, 0 code mismatches, grads <= 7e-3;
+                                  f16mx   z 1.3e-5 - 1.8e-5, recon 2.2e-5, 0 code mismatches, grads <= 7e-3;
                                   bf16    z 3-4e-3, 99.0-99.1 % of codes agree (every flip a reference near-tie with
                                           relative top-2 gap < 1e-3), recon rel-L2 0.05-0.11 (flipped codes), losses 1e-4."""
 import json
@@ -39,8 +40,8 @@ def test_bf16_default_configs_against_reference_golden(mode, tag, golden_dir):
 
 
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
-@pytest.mark.parametrize("mode", ["bf16x3"], indirect=True)
-def test_bf16x3_default_configs_against_reference_golden(mode, tag, golden_dir):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16mx"], indirect=True)
+def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_dir):
     r = run(tag, golden_dir)
     print("g3-%s %s: %s" % (tag, mode, json.dumps(r)))
     flips = 0

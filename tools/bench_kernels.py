@@ -46,6 +46,20 @@ def main():
             line += " bf16 wgrad %7.3f ms %6.1f TF |" % (t, flops / t / 1e9)
             t = timeit(lambda: N.pack_weight(w, N.W_OIK))
             line += " pack %6.3f ms" % t
+        if which in ("all", "bf16x3"):
+            xn, dyn = N.ncl_to_nlc(x, 2), N.ncl_to_nlc(dy, 2)
+            pk = N.pack_weight(w, N.W_OIK, 2)
+            t = timeit(lambda: N.conv1d_bf16(xn, pk, relu=True))
+            line += " x3 fwd %7.3f ms %6.1f TF |" % (t, flops / t / 1e9)
+            t = timeit(lambda: N.conv1d_wgrad_bf16(dyn, xn, KW))
+            line += " x3 wgrad %7.3f ms %6.1f TF |" % (t, flops / t / 1e9)
+        if which in ("all", "f16mx"):
+            xn, dyn = N.ncl_to_nlc(x, 2, "f16mx"), N.ncl_to_nlc(dy, 2, "f16mx")
+            pk = N.pack_weight(w, N.W_OIK, 3)
+            t = timeit(lambda: N.conv1d_bf16(xn, pk, relu=True))
+            line += " f16mx fwd %7.3f ms %6.1f TF |" % (t, flops / t / 1e9)
+            t = timeit(lambda: N.conv1d_wgrad_bf16(dyn, xn, KW))
+            line += " f16mx wgrad %7.3f ms %6.1f TF |" % (t, flops / t / 1e9)
         print(line, flush=True)
 
 
