@@ -1,9 +1,10 @@
 // f16mx convolution (see f16mx_common.h for the format): forward / data-gradient / ConvTranspose of the wide and narrow
 // layers alike, plus the boundary conversions of the format.
 //
-// Tiling and staging are those of conv1d_bf16x3.hip -- 256 out-channels x 256 rows per workgroup, 8 waves, a wave owns
-// 128 x 64; K-tile = (32 channels, one tap) = four 16 KB slabs (W.H, W.Q, X.H, X.Q) in one of two LDS stages filled by
-// LDS-DMA -- but the wave's block is 4 x 2 tiles of 32x32 and a K-tile is TWO phases of 512 matrix-pipe cycles:
+// Tiling is that of conv1d_bf16x3.hip -- 256 out-channels x 256 rows per workgroup, 8 waves, a wave owns 128 x 64;
+// K-tile = (32 channels, one tap) -- with two LDS-DMA rings: the weight slabs (W.H, W.Q; 32 KB) per K-tile and the
+// activation slabs (X.H, X.Q; 34 KB) per CHUNK of 32 channels, shared by the taps as in conv1d_bf16_k3.hip.  The wave's
+// block is 4 x 2 tiles of 32x32 and a K-tile is TWO phases of 512 matrix-pipe cycles:
 //   phase 1  fp16 main term : 2 k-steps x 8 v_mfma_f32_32x32x16_f16          | meanwhile: the Q fragments of this K-tile
 //            s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier    <- K-tile t+1 landed; every read of this stage is done
 //   phase 2  fp8 cross terms: 8 v_mfma_scale_f32_32x32x64_f8f6f4              | meanwhile: DMA of K-tile t+2 into THIS
@@ -18,8 +19,10 @@ namespace alvq {
 
 constexpr int FX_M = 256, FX_R = 256, FX_K = 32;
 constexpr int FX_SLAB = FX_M * FX_K * 2;          // 16384 B
-constexpr int FX_STAGE = 4 * FX_SLAB;             // W.H, W.Q, X.H, X.Q
-constexpr int FX_LDS = 2 * FX_STAGE;              // 131072 B
+constexpr int FX_WSTAGE = 2 * FX_SLAB;            // W.H, W.Q of one K-tile
+constexpr int FX_XSLAB = 272 * 64;                // 272 rows x 64 B (258 used: 256 + a halo row either side)
+constexpr int FX_XSTAGE = 2 * FX_XSLAB;           // X.H, X.Q of one chunk
+constexpr int FX_LDS = 2 * FX_WSTAGE + 2 * FX_XSTAGE;   // 135168 B
 constexpr int FX_CS = FX_M + 4;
 static_assert(64 * FX_CS * 4 <= FX_LDS, "C slab must fit");
 
@@ -48,9 +51,9 @@ __device__ __forceinline__ void fx_load_add16(const u16* p, long plane, long row
   }
 }
 
-__device__ __forceinline__ void fx_store16(u16* p, long plane, long row_elems, int c, float inv_s, float inv_s_lo, const float (&v)[16]) {
+__device__ __forceinline__ void fx_store16(u16* p, long plane, long row_elems, int c, float s_hi, float s_lo, const float (&v)[16]) {
   unsigned h[8], qh[4], ql[4];
-  fx_split<16>(v, inv_s, inv_s_lo, h, qh, ql);
+  fx_split<16>(v, s_hi, s_lo, h, qh, ql);
   *(u32x4*)(p + row_elems + c) = u32x4{h[0], h[1], h[2], h[3]};
   *(u32x4*)(p + row_elems + c + 8) = u32x4{h[4], h[5], h[6], h[7]};
   unsigned char* q = (unsigned char*)(p + plane) + row_elems * 2 + fx_q_off(c);
@@ -68,7 +71,7 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   const ConvBArgs& a = ax.b;
   const int j = lane & 31, h = lane >> 5;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
-  const float s_lo = fx_pow2(ax.eb - FX_LO_SHIFT), inv_s = fx_pow2(254 - ax.eb), inv_s_lo = fx_pow2(254 - ax.eb + FX_LO_SHIFT);
+  const float s_lo = fx_pow2(ax.eb - FX_LO_SHIFT), s_hi = fx_pow2(ax.eb);
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int row = r0 + wn0 + ni * 32 + j;
@@ -92,8 +95,8 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
       if (!ok) {                                         // gap / tail rows stay zero in both planes
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = 0.f;
-        fx_store16(a.y, ax.y_plane, ro, cb, inv_s, inv_s_lo, v);
-        if (a.y2) fx_store16(a.y2, ax.y_plane, ro, cb, inv_s, inv_s_lo, v);
+        fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
+        if (a.y2) fx_store16(a.y2, ax.y_plane, ro, cb, s_hi, s_lo, v);
         continue;
       }
       if (a.bias) {
@@ -116,21 +119,21 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
           v[8 + 2 * e + 1] = fx_h2f_hi(s1[e]) > 0.f ? v[8 + 2 * e + 1] : 0.f;
         }
       }
-      fx_store16(a.y, ax.y_plane, ro, cb, inv_s, inv_s_lo, v);
+      fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
       if (a.y2) {
         fx_load_add16(a.post, ax.y_plane, ro, cb, s_lo, v);
-        fx_store16(a.y2, ax.y_plane, ro, cb, inv_s, inv_s_lo, v);
+        fx_store16(a.y2, ax.y_plane, ro, cb, s_hi, s_lo, v);
       }
     }
   }
 }
 
-template <int OUT, bool DBG = false>
-__global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax, int KW) {
+template <int OUT, int KW, bool DBG = false>
+__global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
+  constexpr int PAD = (KW - 1) / 2;
   const int dbg = DBG ? ax.dbg : 0;
   const ConvBArgs& a = ax.b;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int PAD = (KW - 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
@@ -140,8 +143,11 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax, int
   const int r0 = (tile / a.mtiles) * FX_R;
   const int Cp = a.Cp;
 
-  // ---- DMA: identical to the bf16x3 kernel (a piece is 16 rows x 64 B; lane i -> row i>>2, slot i&3 <- 16-byte group
-  // (i&3) ^ h[(row>>2)&3] of the row's 64-byte chunk); plane 0 = H, plane 1 = Q
+  // ---- DMA (a piece is 16 rows x 64 B; lane i -> row i>>2, slot i&3 <- 16-byte group (i&3) ^ h[(row>>2)&3] of the
+  // row's 64-byte chunk; plane 0 = H, plane 1 = Q).  Two rings: the WEIGHT slabs of one K-tile (32 channels, one tap) and
+  // the ACTIVATION slabs of one CHUNK (32 channels, all taps): rows r0-PAD .. r0+255+PAD are staged once and tap t reads
+  // the slab t rows further down, so a width-3 layer moves 3 x 32 KB of weights + 34 KB of activations per chunk through
+  // LDS-DMA instead of 3 x 64 KB -- a third less DMA issue and L2 -> LDS traffic for the same MFMAs.
   const int hsel = (lane >> 4) & 3;
   const int hval = (hsel == 0) ? 0 : (4 - hsel);
   const int srow = lane >> 2, sgrp = (lane & 3) ^ hval;
@@ -156,47 +162,57 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax, int
   };
   const char* const wb = (const char*)(a.wp + ((long)m0 + wave * 32) * Cp);
   const char* const xb = (const char*)(a.x + ((long)r0 - PAD + wave * 32) * Cp);
-  int is_chunk = 0, is_tap = 0;
-  auto issue = [&](int stage) {
-    const unsigned dst = lds0 + stage * FX_STAGE + wave * 2048;
-    const char* ws = wb + is_tap * tap_w + is_chunk * (FX_K * 2);
-    const char* xs = xb + (long)is_tap * Cp * 2 + is_chunk * (FX_K * 2);
+  constexpr unsigned XBASE = 2 * FX_WSTAGE;
+  auto issueW = [&](int t) {   // K-tile t -> weight stage t & 1: 32 rows of W.H and of W.Q per wave
+    const int chunk = t / KW, tap = t - chunk * KW;
+    const unsigned dst = lds0 + (t & 1) * FX_WSTAGE + wave * 2048;
+    const char* ws = wb + tap * tap_w + chunk * (FX_K * 2);
     dma(ws, dst);
     dma(ws + row16, dst + 1024);
     dma(ws + wpl, dst + FX_SLAB);
     dma(ws + wpl + row16, dst + FX_SLAB + 1024);
-    dma(xs, dst + 2 * FX_SLAB);
-    dma(xs + row16, dst + 2 * FX_SLAB + 1024);
-    dma(xs + xpl, dst + 3 * FX_SLAB);
-    dma(xs + xpl + row16, dst + 3 * FX_SLAB + 1024);
-    if (++is_tap == KW) {
-      is_tap = 0;
-      ++is_chunk;
-    }
+  };
+  auto issueX = [&](int chunk, int plane) {   // one plane of chunk's activation slab -> activation stage chunk & 1
+    const unsigned dst = lds0 + XBASE + (chunk & 1) * FX_XSTAGE + plane * FX_XSLAB + wave * 2048;
+    const char* xs = xb + plane * xpl + chunk * (FX_K * 2);
+    dma(xs, dst);
+    dma(xs + row16, dst + 1024);
+    if (KW == 3 && wave == 7 && srow < 2) dma(xs + 2 * row16, dst + 2048);   // halo: slab rows 256, 257
   };
 
   // ---- fragment reads for the 32x32 shapes: lane (r = lane & 31, g = lane >> 5) takes the 16-byte groups g and 2 + g of
   // row r of a 32-row block.  H slab: group g = k-step 0 (channels 8g..8g+7), group 2+g = k-step 1.  Q slab: group g =
   // hi8[16g..16g+15], group 2+g = lo8[16g..16g+15]; the A operand wants (hi8, lo8), the B operand (lo8, hi8), so that
   // block 0 of the scaled MFMA pairs A.hi8 with B.lo8 and block 1 A.lo8 with B.hi8.  The slot swizzle of the staging
-  // (slot = group ^ {0,3,2,1}[(row>>2)&3]) makes each of these reads conflict-free for this lane pattern too.
+  // (slot = group ^ {0,3,2,1}[(row>>2)&3]) makes the un-shifted reads conflict-free for this lane pattern too; the
+  // activation reads of tap t use slab row r + t.
   const int r32 = lane & 31, g = lane >> 5;
-  const int hq = (r32 >> 2) & 3, hsw = hq == 0 ? 0 : 4 - hq;
-  const int off0 = r32 * 64 + ((g ^ hsw) << 4), off1 = r32 * 64 + (((2 + g) ^ hsw) << 4);
+  int offA[2], offB[KW][2];
+  {
+    const int hq = (r32 >> 2) & 3, hsw = hq == 0 ? 0 : 4 - hq;
+    offA[0] = r32 * 64 + ((g ^ hsw) << 4);
+    offA[1] = r32 * 64 + (((2 + g) ^ hsw) << 4);
+  }
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    const int rr = r32 + t, hq = (rr >> 2) & 3, hsw = hq == 0 ? 0 : 4 - hq;
+    offB[t][0] = rr * 64 + ((g ^ hsw) << 4);
+    offB[t][1] = rr * 64 + (((2 + g) ^ hsw) << 4);
+  }
   const unsigned char* const abase = lds + wm0 * 64;
-  const unsigned char* const bbase = lds + 2 * FX_SLAB + wn0 * 64;
+  const unsigned char* const bbase = lds + XBASE + wn0 * 64;
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   f16x8_t aH[4][2], bH[2][2];
   i32x8 aQ[4], bQ[2];
-#define FX_RDH_A(STAGE, MI, KS) aH[MI][KS] = *(const f16x8_t*)(abase + (STAGE) * FX_STAGE + (MI) * 2048 + ((KS) ? off1 : off0));
-#define FX_RDH_B(STAGE, NI, KS) bH[NI][KS] = *(const f16x8_t*)(bbase + (STAGE) * FX_STAGE + (NI) * 2048 + ((KS) ? off1 : off0));
+#define FX_RDH_A(WS, MI, KS) aH[MI][KS] = *(const f16x8_t*)(abase + (WS) * FX_WSTAGE + (MI) * 2048 + offA[KS]);
+#define FX_RDH_B(XS, TAP, NI, KS) bH[NI][KS] = *(const f16x8_t*)(bbase + (XS) * FX_XSTAGE + (NI) * 2048 + offB[TAP][KS]);
 #define FX_RDQ(DST, P, FIRST, SECOND)                                                           \
   {                                                                                             \
     const i32x4 q0_ = *(const i32x4*)((P) + (FIRST)), q1_ = *(const i32x4*)((P) + (SECOND));    \
     DST = __builtin_shufflevector(q0_, q1_, 0, 1, 2, 3, 4, 5, 6, 7);                            \
   }
-#define FX_RDQ_A(STAGE, MI) FX_RDQ(aQ[MI], abase + (STAGE) * FX_STAGE + FX_SLAB + (MI) * 2048, off0, off1)
-#define FX_RDQ_B(STAGE, NI) FX_RDQ(bQ[NI], bbase + (STAGE) * FX_STAGE + FX_SLAB + (NI) * 2048, off1, off0)
+#define FX_RDQ_A(WS, MI) FX_RDQ(aQ[MI], abase + (WS) * FX_WSTAGE + FX_SLAB + (MI) * 2048, offA[0], offA[1])
+#define FX_RDQ_B(XS, TAP, NI) FX_RDQ(bQ[NI], bbase + (XS) * FX_XSTAGE + FX_XSLAB + (NI) * 2048, offB[TAP][1], offB[TAP][0])
 
   // block scales of the fp8 MFMA: lanes 0-31 supply block 0, lanes 32-63 block 1.  Opaque to the compiler so that it keeps
   // them in registers instead of re-materialising them by VALU moves in front of the inline-asm MFMAs (no hazard padding
@@ -220,44 +236,72 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax, int
           : "+v"(acc[mi][ni]) : "v"(aQ[mi]), "v"(bQ[ni]), "v"(sa), "v"(sb));
 #define FX_SB __builtin_amdgcn_sched_barrier(0);
 
-  const int n = (Cp / FX_K) * KW;   // K-tiles; even (Cp % 64 == 0)
-  const bool early = wave < 4;
+  const int nch = Cp / FX_K;        // chunks; even (Cp % 64 == 0)
+  const int n = nch * KW;           // K-tiles
+  const bool early = wave < 4;      // the two waves of a SIMD issue their DMA at different points of phase 2
 
-  issue(0);
-  issue(1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  // ---- prologue: chunk 0's activation slabs, K-tiles 0 and 1 (and, for width 1, chunk 1's slabs) staged; H fragments of
+  // K-tile 0 in registers
+  issueX(0, 0);
+  issueX(0, 1);
+  issueW(0);
+  if (n > 1) issueW(1);
+  if (KW == 1 && nch > 1) {
+    issueX(1, 0);
+    issueX(1, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) { FX_RDH_A(0, mi, 0) FX_RDH_A(0, mi, 1) }
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) { FX_RDH_B(0, ni, 0) FX_RDH_B(0, ni, 1) }
+  for (int ni = 0; ni < 2; ++ni) { FX_RDH_B(0, 0, ni, 0) FX_RDH_B(0, 0, ni, 1) }
 
-#define FX_TILE(S, MORE)                                                                                                 \
+  // One K-tile: weights in stage WS, activations in stage XS read at tap TAP; the next K-tile's are (NWS, NXS, NTAP).
+  // DMA_ = the DMA this K-tile issues right behind its barrier (the stage its weights occupied is free then).
+#define FX_TILE(WS, XS, TAP, NWS, NXS, NTAP, DMA_)                                                                       \
   FX_MMH(0) FX_SB                                                                                                        \
-  if (!(dbg & 2)) { FX_RDQ_B(S, 0) FX_RDQ_B(S, 1) FX_RDQ_A(S, 0) FX_RDQ_A(S, 1) FX_RDQ_A(S, 2) FX_RDQ_A(S, 3) } FX_SB    \
-  FX_MMH(1) FX_SB                                                                                                        \
+  if (!(dbg & 2)) {                                                                                                      \
+    FX_RDQ_B(XS, TAP, 0) FX_RDQ_B(XS, TAP, 1) FX_RDQ_A(WS, 0) FX_RDQ_A(WS, 1) FX_RDQ_A(WS, 2) FX_RDQ_A(WS, 3)             \
+  }                                                                                                                      \
+  FX_SB FX_MMH(1) FX_SB                                                                                                  \
   if (!(dbg & 4)) {                                                                                                      \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
     __builtin_amdgcn_s_barrier();                                                                                        \
   }                                                                                                                      \
-  if (early && (MORE) && !(dbg & 1)) issue(S);                                                                           \
+  if (early && !(dbg & 1)) { DMA_ }                                                                                      \
   FX_MMQ(0) FX_SB                                                                                                        \
   if (!(dbg & 2)) {                                                                                                      \
-    FX_RDH_B((S) ^ 1, 0, 0) FX_RDH_B((S) ^ 1, 1, 0) FX_RDH_A((S) ^ 1, 0, 0) FX_RDH_A((S) ^ 1, 1, 0)                       \
-    FX_RDH_A((S) ^ 1, 2, 0) FX_RDH_A((S) ^ 1, 3, 0)                                                                      \
+    FX_RDH_B(NXS, NTAP, 0, 0) FX_RDH_B(NXS, NTAP, 1, 0) FX_RDH_A(NWS, 0, 0) FX_RDH_A(NWS, 1, 0)                           \
+    FX_RDH_A(NWS, 2, 0) FX_RDH_A(NWS, 3, 0)                                                                              \
   }                                                                                                                      \
   FX_SB                                                                                                                  \
-  if (!early && (MORE) && !(dbg & 1)) issue(S);                                                                          \
+  if (!early && !(dbg & 1)) { DMA_ }                                                                                     \
   FX_MMQ(2) FX_SB                                                                                                        \
   if (!(dbg & 2)) {                                                                                                      \
-    FX_RDH_B((S) ^ 1, 0, 1) FX_RDH_B((S) ^ 1, 1, 1) FX_RDH_A((S) ^ 1, 0, 1) FX_RDH_A((S) ^ 1, 1, 1)                       \
-    FX_RDH_A((S) ^ 1, 2, 1) FX_RDH_A((S) ^ 1, 3, 1)                                                                      \
+    FX_RDH_B(NXS, NTAP, 0, 1) FX_RDH_B(NXS, NTAP, 1, 1) FX_RDH_A(NWS, 0, 1) FX_RDH_A(NWS, 1, 1)                           \
+    FX_RDH_A(NWS, 2, 1) FX_RDH_A(NWS, 3, 1)                                                                              \
   }                                                                                                                      \
   FX_SB
 
-  for (int t = 0; t < n; t += 2) {
-    FX_TILE(0, t + 2 < n)
-    FX_TILE(1, t + 3 < n)
+  if (KW == 3) {
+    // two chunks (six K-tiles) per iteration so that every stage index is a constant.  The next chunk's activation slabs
+    // are staged behind the barriers of this chunk's taps 0 (H plane) and 1 (Q plane): its stage was released by the
+    // previous chunk's last barrier, and it is first read behind this chunk's last one.
+    for (int c = 0; c < nch; c += 2) {
+      const int t = 3 * c;
+      FX_TILE(0, 0, 0, 1, 0, 1, if (t + 2 < n) issueW(t + 2); if (c + 1 < nch) issueX(c + 1, 0);)
+      FX_TILE(1, 0, 1, 0, 0, 2, if (t + 3 < n) issueW(t + 3); if (c + 1 < nch) issueX(c + 1, 1);)
+      FX_TILE(0, 0, 2, 1, 1, 0, if (t + 4 < n) issueW(t + 4);)
+      FX_TILE(1, 1, 0, 0, 1, 1, if (t + 5 < n) issueW(t + 5); if (c + 2 < nch) issueX(c + 2, 0);)
+      FX_TILE(0, 1, 1, 1, 1, 2, if (t + 6 < n) issueW(t + 6); if (c + 2 < nch) issueX(c + 2, 1);)
+      FX_TILE(1, 1, 2, 0, 0, 0, if (t + 7 < n) issueW(t + 7);)
+    }
+  } else {
+    for (int t = 0; t < n; t += 2) {
+      FX_TILE(0, 0, 0, 1, 1, 0, if (t + 2 < n) { issueW(t + 2); issueX(t + 2, 0); issueX(t + 2, 1); })
+      FX_TILE(1, 1, 0, 0, 0, 0, if (t + 3 < n) { issueW(t + 3); issueX(t + 3, 0); issueX(t + 3, 1); })
+    }
   }
 #undef FX_TILE
 #undef FX_SB
@@ -339,7 +383,7 @@ __global__ __launch_bounds__(256) void ncl_to_nlc_fx_kernel(const float* x, u16*
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = tile[cq + k][rr];
     unsigned h[2], qh[1], ql[1];
-    fx_split<4>(v, fx_pow2(254 - e), fx_pow2(254 - e + FX_LO_SHIFT), h, qh, ql);
+    fx_split<4>(v, fx_pow2(e), fx_pow2(e - FX_LO_SHIFT), h, qh, ql);
     *(u32x2*)(y + (long)row * Cp + c0 + cq) = u32x2{h[0], h[1]};
     unsigned char* q = (unsigned char*)(y + plane) + (long)row * Cp * 2 + fx_q_off(c0) + cq;
     *(unsigned*)q = qh[0];
@@ -508,16 +552,25 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
   hipStream_t s = (hipStream_t)stream;
   static DeviceOnce attr;
   if (attr.need()) {
-    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
-    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
-    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
   }
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
   if (dbg_env && y) {
-    hipLaunchKernelGGL((conv1d_f16mx_kernel<0, true>), grid, block, FX_LDS, s, a, KW);
+    if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, true>), grid, block, FX_LDS, s, a);
+    else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, true>), grid, block, FX_LDS, s, a);
     return check_launch("alvq_conv1d_f16mx(dbg)");
   }
-  if (y) hipLaunchKernelGGL((conv1d_f16mx_kernel<0>), grid, block, FX_LDS, s, a, KW);
-  else hipLaunchKernelGGL((conv1d_f16mx_kernel<1>), grid, block, FX_LDS, s, a, KW);
+  if (y) {
+    if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3>), grid, block, FX_LDS, s, a);
+    else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1>), grid, block, FX_LDS, s, a);
+  } else {
+    if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<1, 3>), grid, block, FX_LDS, s, a);
+    else hipLaunchKernelGGL((conv1d_f16mx_kernel<1, 1>), grid, block, FX_LDS, s, a);
+  }
   return check_launch("alvq_conv1d_f16mx");
 }

@@ -45,25 +45,28 @@ constexpr int FX_LO_SHIFT = 11;    // lo8 is scaled by S * 2^-11
 
 __device__ __forceinline__ float fx_pow2(int e) { return __uint_as_float((unsigned)e << 23); }   // 2^(e-127), 1 <= e <= 254
 
-// two floats -> packed fp16 pair (RNE), saturating at +-65504 instead of overflowing to infinity
+// two floats -> packed fp16 pair (RNE), saturating at +-65504 instead of overflowing to infinity (v_med3_f32 clamps)
 __device__ __forceinline__ unsigned fx_f16_pk(float a, float b) {
   const float m = 65504.f;
-  const f32x2 f = {__builtin_fminf(__builtin_fmaxf(a, -m), m), __builtin_fminf(__builtin_fmaxf(b, -m), m)};
+  const f32x2 f = {__builtin_amdgcn_fmed3f(a, -m, m), __builtin_amdgcn_fmed3f(b, -m, m)};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2_t));
 }
 __device__ __forceinline__ float fx_h2f_lo(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[0]; }
 __device__ __forceinline__ float fx_h2f_hi(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[1]; }
 
-// four floats -> four e4m3 bytes (RNE), saturating at +-448 (the bare conversion returns NaN above 464)
-__device__ __forceinline__ unsigned fx_fp8x4(float a, float b, float c, float d) {
-  const float m = 448.f;
-  a = __builtin_fminf(__builtin_fmaxf(a, -m), m);
-  b = __builtin_fminf(__builtin_fmaxf(b, -m), m);
-  c = __builtin_fminf(__builtin_fmaxf(c, -m), m);
-  d = __builtin_fminf(__builtin_fmaxf(d, -m), m);
-  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-  return (unsigned)r;
+// four floats -> four e4m3 bytes of v / s (RNE; s a power of two), saturating at +-448 s (the bare conversion returns NaN
+// above 464).  v_cvt_scalef32_pk_fp8_f32 divides by the scale inside the conversion.
+__device__ __forceinline__ unsigned fx_fp8x4(float a, float b, float c, float d, float s) {
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  const float m = 448.f * s;
+  a = __builtin_amdgcn_fmed3f(a, -m, m);
+  b = __builtin_amdgcn_fmed3f(b, -m, m);
+  c = __builtin_amdgcn_fmed3f(c, -m, m);
+  d = __builtin_amdgcn_fmed3f(d, -m, m);
+  s16x2_t r = {0, 0};
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a, b, s, false);
+  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, s, true);
+  return __builtin_bit_cast(unsigned, r);
 }
 
 // e4m3 byte -> float (exact); on gfx950 v_cvt_f32_fp8 with byte select
@@ -76,9 +79,9 @@ __device__ __forceinline__ float fx_fp8_to_f(unsigned word, int byte) {
   }
 }
 
-// Split N (multiple of 4) consecutive values: h[N/2] packed fp16 pairs, qh[N/4] / ql[N/4] packed fp8 quads.
+// Split N (multiple of 4) consecutive values: h[N/2] packed fp16 pairs, qh[N/4] = e4m3(v / s), ql[N/4] = e4m3((v - H) / s_lo).
 template <int N>
-__device__ __forceinline__ void fx_split(const float (&v)[N], float inv_s, float inv_s_lo, unsigned (&h)[N / 2], unsigned (&qh)[N / 4],
+__device__ __forceinline__ void fx_split(const float (&v)[N], float s, float s_lo, unsigned (&h)[N / 2], unsigned (&qh)[N / 4],
                                          unsigned (&ql)[N / 4]) {
   float lo[N];
 #pragma unroll
@@ -89,8 +92,8 @@ __device__ __forceinline__ void fx_split(const float (&v)[N], float inv_s, float
   }
 #pragma unroll
   for (int e = 0; e < N / 4; ++e) {
-    qh[e] = fx_fp8x4(v[4 * e] * inv_s, v[4 * e + 1] * inv_s, v[4 * e + 2] * inv_s, v[4 * e + 3] * inv_s);
-    ql[e] = fx_fp8x4(lo[4 * e] * inv_s_lo, lo[4 * e + 1] * inv_s_lo, lo[4 * e + 2] * inv_s_lo, lo[4 * e + 3] * inv_s_lo);
+    qh[e] = fx_fp8x4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3], s);
+    ql[e] = fx_fp8x4(lo[4 * e], lo[4 * e + 1], lo[4 * e + 2], lo[4 * e + 3], s_lo);
   }
 }
 

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackBatch b) {
     for (int e = 0; e < 8; ++e) v[e] = tile[t][mr][cg + e];
     if (PLANES == 3) {   // f16mx: H image (fp16) + Q image ([hi8 x 32 | lo8 x 32] per 32 channels), weight-class scale
       unsigned h[4], qh[2], ql[2];
-      fx_split<8>(v, fx_pow2(254 - FX_E_W), fx_pow2(254 - FX_E_W + FX_LO_SHIFT), h, qh, ql);
+      fx_split<8>(v, fx_pow2(FX_E_W), fx_pow2(FX_E_W - FX_LO_SHIFT), h, qh, ql);
       *(u32x4*)(d.wp + o) = u32x4{h[0], h[1], h[2], h[3]};
       unsigned char* q = (unsigned char*)(d.wp + b.plane[di]) + ((long)t * d.Mp + m0 + mr) * d.Cp * 2 + fx_q_off(c0 + cg);
       *(u32x2*)q = u32x2{qh[0], qh[1]};
