@@ -23,10 +23,7 @@ namespace alvq {
 
 constexpr int X3_M = 256, X3_R = 256, X3_K = 32;
 constexpr int X3_SLAB = X3_M * X3_K * 2;          // 16384 B
-constexpr int X3_STAGE = 4 * X3_SLAB;             // A_hi, A_lo, B_hi, B_lo
-constexpr int X3_LDS = 2 * X3_STAGE;              // 131072 B
 constexpr int X3_CS = X3_M + 4;
-static_assert(64 * X3_CS * 4 <= X3_LDS, "C slab must fit");
 
 struct ConvX3Args {
   ConvBArgs b;          // hi planes (and everything shared)
@@ -108,24 +105,32 @@ __device__ __forceinline__ void wave_epilogue_x3(const ConvX3Args& ax, const f32
   }
 }
 
-// Main kernel.  A K-tile = (32 channels, one tap) = four 16 KB slabs (W hi, W lo, X hi, X lo) in one of two LDS stages;
-// per wave it is three phases of 32 MFMAs on the same 8 x 4 accumulators:
+// Main kernel.  A K-tile = (32 channels, one tap).  Two LDS-DMA rings: the WEIGHT slabs of a K-tile (W hi, W lo; 32 KB, two
+// stages) and the ACTIVATION slabs of a CHUNK of 32 channels (X hi, X lo; rows r0-PAD .. r0+255+PAD staged once, 34 KB,
+// two stages) -- tap t reads the slab t rows further down, as in conv1d_bf16_k3.hip, so a width-3 layer moves a third
+// less through LDS-DMA.  Per wave a K-tile is three phases of 32 MFMAs on the same 8 x 4 accumulators:
 //   phase 1  hi*hi : A0 = W hi fragments, BX = X hi        | meanwhile: read X lo -> BY, first half of W lo -> A1
 //   phase 2  hi*lo : A0, BY                                 | meanwhile: second half of W lo -> A1
-//            s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      <- K-tile t+1 has landed; every read of this stage is done
-//   phase 3  lo*hi : A1, BX                                 | meanwhile: DMA of K-tile t+2 into THIS stage; the hi
-//                                                             fragments of K-tile t+1 -> A0 (dead since phase 2) and BY
+//            s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier      <- K-tile t+1 has landed; every read of this K-tile is done
+//   phase 3  lo*hi : A1, BX                                 | meanwhile: DMA of K-tile t+2's weights into THIS weight
+//                                                             stage (and, on taps 0 / 1, of the next chunk's activation
+//                                                             planes); the hi fragments of K-tile t+1 -> A0 and BY
 // so the barrier falls between phases whose operands are already in registers: no fragment read is ever exposed
-// behind it, every LDS read has at least half a phase (16 MFMAs) to return, every DMA piece has three phases to land
-// and the X fragment sets swap roles from one K-tile to the next (BX <-> BY).  96 fragment VGPRs + 128 accumulators.
-// MFMAs are tied inline asm (hipcc does not tie the builtin's destination to its C operand and then shuffles the
-// accumulators through spare registers it does not have here); DMA pieces are inline asm with a scalar base and one
-// 32-bit lane offset, as in conv1d_bf16_k3.hip.
-template <int OUT>
-__global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, int KW) {
+// behind it, every LDS read has at least half a phase (16 MFMAs) to return, and the X fragment sets swap roles from
+// one K-tile to the next (BX <-> BY).  96 fragment VGPRs + 128 accumulators.  MFMAs are tied inline asm (hipcc does
+// not tie the builtin's destination to its C operand and then shuffles the accumulators through spare registers it
+// does not have here); DMA pieces are inline asm with a scalar base and one 32-bit lane offset.
+constexpr int X3_WSTAGE = 2 * X3_SLAB;            // W hi, W lo of one K-tile
+constexpr int X3_XSLAB = 272 * 64;                // 272 rows x 64 B (258 used)
+constexpr int X3_XSTAGE = 2 * X3_XSLAB;           // X hi, X lo of one chunk
+constexpr int X3_LDS2 = 2 * X3_WSTAGE + 2 * X3_XSTAGE;   // 135168 B
+static_assert(64 * X3_CS * 4 <= X3_LDS2, "C slab must fit");
+
+template <int OUT, int KW>
+__global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
+  constexpr int PAD = (KW - 1) / 2;
   const ConvBArgs& a = ax.b;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int PAD = (KW - 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
@@ -151,38 +156,44 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, in
   };
   const char* const wb = (const char*)(a.wp + ((long)m0 + wave * 32) * Cp);
   const char* const xb = (const char*)(a.x + ((long)r0 - PAD + wave * 32) * Cp);
-  int is_chunk = 0, is_tap = 0;   // K-tile the next issue() stages
-  auto issue = [&](int stage) {   // 8 pieces per wave: 32 rows of each slab
-    const unsigned dst = lds0 + stage * X3_STAGE + wave * 2048;
-    const char* ws = wb + is_tap * tap_w + is_chunk * (X3_K * 2);
-    const char* xs = xb + (long)is_tap * Cp * 2 + is_chunk * (X3_K * 2);
+  constexpr unsigned XBASE = 2 * X3_WSTAGE;
+  auto issueW = [&](int t) {   // K-tile t -> weight stage t & 1: 32 rows of W hi and of W lo per wave
+    const int chunk = t / KW, tap = t - chunk * KW;
+    const unsigned dst = lds0 + (t & 1) * X3_WSTAGE + wave * 2048;
+    const char* ws = wb + tap * tap_w + chunk * (X3_K * 2);
     dma(ws, dst);
     dma(ws + row16, dst + 1024);
     dma(ws + wpl, dst + X3_SLAB);
     dma(ws + wpl + row16, dst + X3_SLAB + 1024);
-    dma(xs, dst + 2 * X3_SLAB);
-    dma(xs + row16, dst + 2 * X3_SLAB + 1024);
-    dma(xs + xpl, dst + 3 * X3_SLAB);
-    dma(xs + xpl + row16, dst + 3 * X3_SLAB + 1024);
-    if (++is_tap == KW) {
-      is_tap = 0;
-      ++is_chunk;
-    }
+  };
+  auto issueX = [&](int chunk, int plane) {   // one plane of a chunk's activation slab -> activation stage chunk & 1
+    const unsigned dst = lds0 + XBASE + (chunk & 1) * X3_XSTAGE + plane * X3_XSLAB + wave * 2048;
+    const char* xs = xb + plane * xpl + chunk * (X3_K * 2);
+    dma(xs, dst);
+    dma(xs + row16, dst + 1024);
+    if (KW == 3 && wave == 7 && srow < 2) dma(xs + 2 * row16, dst + 2048);   // halo: slab rows 256, 257
   };
 
-  // ---- fragment reads (same lane offset for both operands; plane 0 = hi, 1 = lo)
-  const int loff = li * 64 + ((kq ^ ((((li >> 2) & 3) == 0) ? 0 : (4 - ((li >> 2) & 3)))) << 4);
-  const unsigned char* const abase = lds + wm0 * 64 + loff;
-  const unsigned char* const bbase = lds + 2 * X3_SLAB + wn0 * 64 + loff;
+  // ---- fragment reads (plane 0 = hi, 1 = lo); activations of tap t: slab row = local row + t
+  const int hl = (li >> 2) & 3;
+  const int loffA = li * 64 + ((kq ^ (hl == 0 ? 0 : 4 - hl)) << 4);
+  int loffB[KW];
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    const int r = li + t, h = (r >> 2) & 3;
+    loffB[t] = r * 64 + ((kq ^ (h == 0 ? 0 : 4 - h)) << 4);
+  }
+  const unsigned char* const abase = lds + wm0 * 64 + loffA;
+  const unsigned char* const bbase = lds + XBASE + wn0 * 64;
   bf16x8_t fa0[8], fa1[8], fb0[4], fb1[4];
-#define X3_RDA(DST, HALF, STAGE, PLANE)                                                            \
+#define X3_RDA(DST, HALF, WS, PLANE)                                                               \
   {                                                                                                \
-    const unsigned char* pa_ = abase + (STAGE) * X3_STAGE + (PLANE) * X3_SLAB;                     \
+    const unsigned char* pa_ = abase + (WS) * X3_WSTAGE + (PLANE) * X3_SLAB;                       \
     _Pragma("unroll") for (int mi = (HALF) * 4; mi < (HALF) * 4 + 4; ++mi) DST[mi] = *(const bf16x8_t*)(pa_ + mi * 1024); \
   }
-#define X3_RDB(DST, STAGE, PLANE)                                                                  \
+#define X3_RDB(DST, XS, TAP, PLANE)                                                                \
   {                                                                                                \
-    const unsigned char* pb_ = bbase + (STAGE) * X3_STAGE + (PLANE) * X3_SLAB;                     \
+    const unsigned char* pb_ = bbase + (XS) * X3_XSTAGE + (PLANE) * X3_XSLAB + loffB[TAP];         \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) DST[ni] = *(const bf16x8_t*)(pb_ + ni * 1024); \
   }
 
@@ -197,34 +208,56 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, in
       asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(A[mi]), "v"(B[ni]));
 #define X3_SB __builtin_amdgcn_sched_barrier(0);
 
-  const int n = (Cp / X3_K) * KW;   // K-tiles; even (Cp % 64 == 0)
+  const int nch = Cp / X3_K;        // chunks; even (Cp % 64 == 0)
+  const int n = nch * KW;           // K-tiles
   const bool early = wave < 4;      // the two waves of a SIMD issue their DMA at different points of phase 3
 
-  // ---- prologue: K-tile 0 landed, K-tile 1 in flight, hi fragments of K-tile 0 in A0 / fb0
-  issue(0);
-  issue(1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  // ---- prologue: chunk 0's activation slabs, K-tiles 0 and 1 (and, for width 1, chunk 1's slabs) staged; hi fragments
+  // of K-tile 0 in A0 / fb0
+  issueX(0, 0);
+  issueX(0, 1);
+  issueW(0);
+  if (n > 1) issueW(1);
+  if (KW == 1 && nch > 1) {
+    issueX(1, 0);
+    issueX(1, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   X3_RDA(fa0, 0, 0, 0)
   X3_RDA(fa0, 1, 0, 0)
-  X3_RDB(fb0, 0, 0)
+  X3_RDB(fb0, 0, 0, 0)
 
-  // one K-tile in stage S with X hi in BX; BY receives X lo and, in phase 3, the next K-tile's X hi
-#define X3_TILE(S, BX, BY, MORE)                                                                   \
-  X3_MM(fa0, BX, 0) X3_SB X3_RDB(BY, S, 1) X3_SB                                                   \
-  X3_MM(fa0, BX, 1) X3_SB X3_RDA(fa1, 0, S, 1) X3_SB                                               \
-  X3_MM(fa0, BY, 0) X3_SB X3_RDA(fa1, 1, S, 1) X3_SB                                               \
+  // one K-tile: weights in stage WS, activations in stage XS at tap TAP, X hi in BX; BY receives X lo and, in phase 3,
+  // the next K-tile's X hi (NWS, NXS, NTAP).  DMA_ = what this K-tile stages right behind its barrier.
+#define X3_TILE(WS, XS, TAP, NWS, NXS, NTAP, BX, BY, DMA_)                                         \
+  X3_MM(fa0, BX, 0) X3_SB X3_RDB(BY, XS, TAP, 1) X3_SB                                             \
+  X3_MM(fa0, BX, 1) X3_SB X3_RDA(fa1, 0, WS, 1) X3_SB                                              \
+  X3_MM(fa0, BY, 0) X3_SB X3_RDA(fa1, 1, WS, 1) X3_SB                                              \
   X3_MM(fa0, BY, 1) X3_SB                                                                          \
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
   __builtin_amdgcn_s_barrier();                                                                    \
-  if (early && (MORE)) issue(S);                                                                   \
-  X3_MM(fa1, BX, 0) X3_SB X3_RDA(fa0, 0, (S) ^ 1, 0) X3_RDB(BY, (S) ^ 1, 0) X3_SB                  \
-  if (!early && (MORE)) issue(S);                                                                  \
-  X3_MM(fa1, BX, 1) X3_SB X3_RDA(fa0, 1, (S) ^ 1, 0) X3_SB
+  if (early) { DMA_ }                                                                              \
+  X3_MM(fa1, BX, 0) X3_SB X3_RDA(fa0, 0, NWS, 0) X3_RDB(BY, NXS, NTAP, 0) X3_SB                    \
+  if (!early) { DMA_ }                                                                             \
+  X3_MM(fa1, BX, 1) X3_SB X3_RDA(fa0, 1, NWS, 0) X3_SB
 
-  for (int t = 0; t < n; t += 2) {
-    X3_TILE(0, fb0, fb1, t + 2 < n)
-    X3_TILE(1, fb1, fb0, t + 3 < n)
+  if (KW == 3) {
+    // two chunks (six K-tiles) per iteration: every stage index and the BX / BY roles are constants
+    for (int c = 0; c < nch; c += 2) {
+      const int t = 3 * c;
+      X3_TILE(0, 0, 0, 1, 0, 1, fb0, fb1, if (t + 2 < n) issueW(t + 2); if (c + 1 < nch) issueX(c + 1, 0);)
+      X3_TILE(1, 0, 1, 0, 0, 2, fb1, fb0, if (t + 3 < n) issueW(t + 3); if (c + 1 < nch) issueX(c + 1, 1);)
+      X3_TILE(0, 0, 2, 1, 1, 0, fb0, fb1, if (t + 4 < n) issueW(t + 4);)
+      X3_TILE(1, 1, 0, 0, 1, 1, fb1, fb0, if (t + 5 < n) issueW(t + 5); if (c + 2 < nch) issueX(c + 2, 0);)
+      X3_TILE(0, 1, 1, 1, 1, 2, fb0, fb1, if (t + 6 < n) issueW(t + 6); if (c + 2 < nch) issueX(c + 2, 1);)
+      X3_TILE(1, 1, 2, 0, 0, 0, fb1, fb0, if (t + 7 < n) issueW(t + 7);)
+    }
+  } else {
+    for (int t = 0; t < n; t += 2) {
+      X3_TILE(0, 0, 0, 1, 1, 0, fb0, fb1, if (t + 2 < n) { issueW(t + 2); issueX(t + 2, 0); issueX(t + 2, 1); })
+      X3_TILE(1, 1, 0, 0, 0, 0, fb1, fb0, if (t + 3 < n) { issueW(t + 3); issueX(t + 3, 0); issueX(t + 3, 1); })
+    }
   }
 #undef X3_TILE
 #undef X3_SB
@@ -240,131 +273,6 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax, in
     return;
   }
   __syncthreads();   // the C slab overlays the stages: the trailing fragment reads of every wave must be done
-  // ---- OUT == 1 (fp32 NCL, bias only): four 64-row slabs through an fp32 LDS tile
-  float* Cs = (float*)lds;
-  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
-  for (int slab = 0; slab < 4; ++slab) {
-    if ((wave & 3) == slab) {
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int rl = ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
-          *(f32x4*)(Cs + rl * X3_CS + ml) = acc[mi][ni];
-        }
-    }
-    __syncthreads();
-    {
-      const int rl = tid & 63, row = r0 + slab * 64 + rl;
-      int b, l;
-      if (row_valid(row, Lp1, ndata, &b, &l)) {
-        for (int ml = tid >> 6; ml < X3_M; ml += 8) {
-          const int m = m0 + ml;
-          if (m >= a.M) break;
-          a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * X3_CS + ml] + (a.bias ? a.bias[m] : 0.f);
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-template <int OUT>
-__global__ __launch_bounds__(512, 2) void conv1d_bf16x3_old_kernel(ConvX3Args ax, int KW) {
-  const ConvBArgs& a = ax.b;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int PAD = (KW - 1) / 2;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, kq = lane >> 4;
-  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
-
-  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int m0 = (tile % a.mtiles) * X3_M;
-  const int r0 = (tile / a.mtiles) * X3_R;
-  const int Cp = a.Cp;
-
-  const int hsel = (lane >> 4) & 3;
-  const int hval = (hsel == 0) ? 0 : (4 - hsel);
-  const int srow = lane >> 2, sgrp = (lane & 3) ^ hval;
-  const long lane_off = (long)srow * Cp + sgrp * 8;
-  const u16* const wbase = a.wp + ((long)m0 + wave * 32) * Cp + lane_off;
-  const u16* const xbase = a.x + ((long)r0 - PAD + wave * 32) * Cp + lane_off;
-  const long tap_w = (long)a.Mp128 * Cp;
-
-  int is_chunk = 0, is_tap = 0;
-  auto issue = [&](int stage) {   // 8 pieces per wave: two per slab
-    unsigned char* dst = lds + stage * X3_STAGE + wave * 2048;
-    const u16* ws = wbase + is_tap * tap_w + is_chunk * X3_K;
-    const u16* xs = xbase + (long)is_tap * Cp + is_chunk * X3_K;
-    glds16(ws, dst);
-    glds16(ws + 16L * Cp, dst + 1024);
-    glds16(ws + ax.wp_plane, dst + X3_SLAB);
-    glds16(ws + ax.wp_plane + 16L * Cp, dst + X3_SLAB + 1024);
-    glds16(xs, dst + 2 * X3_SLAB);
-    glds16(xs + 16L * Cp, dst + 2 * X3_SLAB + 1024);
-    glds16(xs + ax.x_plane, dst + 3 * X3_SLAB);
-    glds16(xs + ax.x_plane + 16L * Cp, dst + 3 * X3_SLAB + 1024);
-    if (++is_tap == KW) {
-      is_tap = 0;
-      ++is_chunk;
-    }
-  };
-
-  const int loff = li * 64 + ((kq ^ ((((li >> 2) & 3) == 0) ? 0 : (4 - ((li >> 2) & 3)))) << 4);
-  const unsigned char* const abase = lds + wm0 * 64 + loff;                       // A_hi; A_lo at + X3_SLAB
-  const unsigned char* const bbase = lds + 2 * X3_SLAB + wn0 * 64 + loff;         // B_hi; B_lo at + X3_SLAB
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int n = (Cp / X3_K) * KW;
-  issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (int t = 0; t < n; ++t) {
-    const int stage = t & 1;
-    if (t + 1 < n) issue(stage ^ 1);     // lands during this K-tile's 96 MFMAs
-    const unsigned char* pa = abase + stage * X3_STAGE;
-    const unsigned char* pb = bbase + stage * X3_STAGE;
-    bf16x8_t ah[8], al[8], bh[4], bl[4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) ah[mi] = *(const bf16x8_t*)(pa + mi * 1024);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bh[ni] = *(const bf16x8_t*)(pb + ni * 1024);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) bl[ni] = *(const bf16x8_t*)(pb + X3_SLAB + ni * 1024);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) al[mi] = *(const bf16x8_t*)(pa + X3_SLAB + mi * 1024);   // in flight under hi*lo
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  if (OUT == 0) {   // bf16 hi + lo planes, straight from the accumulators
-    wave_epilogue_x3(ax, acc, m0, r0, li, kq, wm0, wn0);
-    return;
-  }
   // ---- OUT == 1 (fp32 NCL, bias only): four 64-row slabs through an fp32 LDS tile
   float* Cs = (float*)lds;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
@@ -789,20 +697,19 @@ extern "C" int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bi
   hipStream_t s = (hipStream_t)stream;
   static DeviceOnce attr;
   if (attr.need()) {
-    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
-    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
-    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_old_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
-    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_old_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
   }
-  static const bool use_old = getenv("ALVQ_X3_OLD") && atoi(getenv("ALVQ_X3_OLD")) != 0;    // A/B switch (temporary)
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
-  if (use_old) {
-    if (y) hipLaunchKernelGGL((conv1d_bf16x3_old_kernel<0>), grid, block, X3_LDS, s, a, KW);
-    else hipLaunchKernelGGL((conv1d_bf16x3_old_kernel<1>), grid, block, X3_LDS, s, a, KW);
-    return check_launch("alvq_conv1d_bf16x3");
+  if (y) {
+    if (KW == 3) hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 3>), grid, block, X3_LDS2, s, a);
+    else hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 1>), grid, block, X3_LDS2, s, a);
+  } else {
+    if (KW == 3) hipLaunchKernelGGL((conv1d_bf16x3_kernel<1, 3>), grid, block, X3_LDS2, s, a);
+    else hipLaunchKernelGGL((conv1d_bf16x3_kernel<1, 1>), grid, block, X3_LDS2, s, a);
   }
-  if (y) hipLaunchKernelGGL((conv1d_bf16x3_kernel<0>), grid, block, X3_LDS, s, a, KW);
-  else hipLaunchKernelGGL((conv1d_bf16x3_kernel<1>), grid, block, X3_LDS, s, a, KW);
   return check_launch("alvq_conv1d_bf16x3");
 }
 
