@@ -163,21 +163,30 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   const char* const wb = (const char*)(a.wp + ((long)m0 + wave * 32) * Cp);
   const char* const xb = (const char*)(a.x + ((long)r0 - PAD + wave * 32) * Cp);
   constexpr unsigned XBASE = 2 * FX_WSTAGE;
-  auto issueW = [&](int t) {   // K-tile t -> weight stage t & 1: 32 rows of W.H and of W.Q per wave
+  // K-tile t -> weight stage t & 1: 32 rows of W.H and of W.Q per wave = pieces 0..3 (issued one at a time so that each
+  // can sit in the shadow of an MFMA)
+  auto pieceW = [&](int t, int k) {
     const int chunk = t / KW, tap = t - chunk * KW;
-    const unsigned dst = lds0 + (t & 1) * FX_WSTAGE + wave * 2048;
-    const char* ws = wb + tap * tap_w + chunk * (FX_K * 2);
-    dma(ws, dst);
-    dma(ws + row16, dst + 1024);
-    dma(ws + wpl, dst + FX_SLAB);
-    dma(ws + wpl + row16, dst + FX_SLAB + 1024);
+    const unsigned dst = lds0 + (t & 1) * FX_WSTAGE + wave * 2048 + (k >> 1) * FX_SLAB + (k & 1) * 1024;
+    dma(wb + tap * tap_w + chunk * (FX_K * 2) + (k >> 1) * wpl + (k & 1) * row16, dst);
   };
-  auto issueX = [&](int chunk, int plane) {   // one plane of chunk's activation slab -> activation stage chunk & 1
+  auto issueW = [&](int t) {
+    pieceW(t, 0);
+    pieceW(t, 1);
+    pieceW(t, 2);
+    pieceW(t, 3);
+  };
+  // one plane of a chunk's activation slab -> activation stage chunk & 1: pieces 0, 1 (+ the halo rows 256, 257)
+  auto pieceX = [&](int chunk, int plane, int k) {
     const unsigned dst = lds0 + XBASE + (chunk & 1) * FX_XSTAGE + plane * FX_XSLAB + wave * 2048;
     const char* xs = xb + plane * xpl + chunk * (FX_K * 2);
-    dma(xs, dst);
-    dma(xs + row16, dst + 1024);
-    if (KW == 3 && wave == 7 && srow < 2) dma(xs + 2 * row16, dst + 2048);   // halo: slab rows 256, 257
+    if (k < 2) dma(xs + k * row16, dst + k * 1024);
+    else if (KW == 3 && wave == 7 && srow < 2) dma(xs + 2 * row16, dst + 2048);
+  };
+  auto issueX = [&](int chunk, int plane) {
+    pieceX(chunk, plane, 0);
+    pieceX(chunk, plane, 1);
+    pieceX(chunk, plane, 2);
   };
 
   // ---- fragment reads for the 32x32 shapes: lane (r = lane & 31, g = lane >> 5) takes the 16-byte groups g and 2 + g of
@@ -227,13 +236,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
-#define FX_MMH(KS)                                                                                                       \
-  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                      \
-      asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(aH[mi][KS]), "v"(bH[ni][KS]));
-#define FX_MMQ(MI0)                                                                                                      \
-  _Pragma("unroll") for (int mi = (MI0); mi < (MI0) + 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)          \
-      asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"                                   \
-          : "+v"(acc[mi][ni]) : "v"(aQ[mi]), "v"(bQ[ni]), "v"(sa), "v"(sb));
+#define FX_H(MI, NI, KS) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[MI][NI]) : "v"(aH[MI][KS]), "v"(bH[NI][KS]));
+#define FX_Q(MI, NI)                                                                       \
+  asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"         \
+      : "+v"(acc[MI][NI]) : "v"(aQ[MI]), "v"(bQ[NI]), "v"(sa), "v"(sb));
 #define FX_SB __builtin_amdgcn_sched_barrier(0);
 
   const int nch = Cp / FX_K;        // chunks; even (Cp % 64 == 0)
@@ -258,31 +264,36 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   for (int ni = 0; ni < 2; ++ni) { FX_RDH_B(0, 0, ni, 0) FX_RDH_B(0, 0, ni, 1) }
 
   // One K-tile: weights in stage WS, activations in stage XS read at tap TAP; the next K-tile's are (NWS, NXS, NTAP).
-  // DMA_ = the DMA this K-tile issues right behind its barrier (the stage its weights occupied is free then).
-#define FX_TILE(WS, XS, TAP, NWS, NXS, NTAP, DMA_)                                                                       \
-  FX_MMH(0) FX_SB                                                                                                        \
-  if (!(dbg & 2)) {                                                                                                      \
-    FX_RDQ_B(XS, TAP, 0) FX_RDQ_B(XS, TAP, 1) FX_RDQ_A(WS, 0) FX_RDQ_A(WS, 1) FX_RDQ_A(WS, 2) FX_RDQ_A(WS, 3)             \
-  }                                                                                                                      \
-  FX_SB FX_MMH(1) FX_SB                                                                                                  \
+  // TW = the K-tile whose weights are staged behind this tile's barrier (into the weight stage this tile occupied), or
+  // -1; XC / XP = chunk and plane of the activation slab staged here, or XC = -1.
+  // Every LDS read and every DMA piece sits in the shadow of ONE MFMA (at most two 16-byte reads or one DMA piece plus
+  // two reads per gap): issued in bursts -- all twelve reads of a phase in a row, by both waves of a SIMD at the same
+  // point of the program -- they left the matrix pipe idle for the length of the burst (measured: 17 % of the kernel).
+  // Reads are ordered by first use; the early / late halves of the workgroup place their DMA pieces in different gaps.
+#define FX_RD(X_) if (!(dbg & 2)) { X_ }
+#define FX_DMA_E(X_) if (early && !(dbg & 1)) { X_ }
+#define FX_DMA_L(X_) if (!early && !(dbg & 1)) { X_ }
+#define FX_TILE(WS, XS, TAP, NWS, NXS, NTAP, TW, XC, XP)                                                                 \
+  FX_H(0, 0, 0) FX_SB FX_RD(FX_RDQ_B(XS, TAP, 0)) FX_SB                                                                   \
+  FX_H(0, 1, 0) FX_SB FX_RD(FX_RDQ_A(WS, 0)) FX_SB                                                                        \
+  FX_H(1, 0, 0) FX_SB FX_RD(FX_RDQ_B(XS, TAP, 1)) FX_SB                                                                   \
+  FX_H(1, 1, 0) FX_SB FX_RD(FX_RDQ_A(WS, 1)) FX_SB                                                                        \
+  FX_H(2, 0, 0) FX_SB FX_RD(FX_RDQ_A(WS, 2)) FX_SB                                                                        \
+  FX_H(2, 1, 0) FX_SB FX_RD(FX_RDQ_A(WS, 3)) FX_SB                                                                        \
+  FX_H(3, 0, 0) FX_H(3, 1, 0)                                                                                            \
+  FX_H(0, 0, 1) FX_H(0, 1, 1) FX_H(1, 0, 1) FX_H(1, 1, 1) FX_H(2, 0, 1) FX_H(2, 1, 1) FX_H(3, 0, 1) FX_H(3, 1, 1) FX_SB   \
   if (!(dbg & 4)) {                                                                                                      \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                          \
     __builtin_amdgcn_s_barrier();                                                                                        \
   }                                                                                                                      \
-  if (early && !(dbg & 1)) { DMA_ }                                                                                      \
-  FX_MMQ(0) FX_SB                                                                                                        \
-  if (!(dbg & 2)) {                                                                                                      \
-    FX_RDH_B(NXS, NTAP, 0, 0) FX_RDH_B(NXS, NTAP, 1, 0) FX_RDH_A(NWS, 0, 0) FX_RDH_A(NWS, 1, 0)                           \
-    FX_RDH_A(NWS, 2, 0) FX_RDH_A(NWS, 3, 0)                                                                              \
-  }                                                                                                                      \
-  FX_SB                                                                                                                  \
-  if (!early && !(dbg & 1)) { DMA_ }                                                                                     \
-  FX_MMQ(2) FX_SB                                                                                                        \
-  if (!(dbg & 2)) {                                                                                                      \
-    FX_RDH_B(NXS, NTAP, 0, 1) FX_RDH_B(NXS, NTAP, 1, 1) FX_RDH_A(NWS, 0, 1) FX_RDH_A(NWS, 1, 1)                           \
-    FX_RDH_A(NWS, 2, 1) FX_RDH_A(NWS, 3, 1)                                                                              \
-  }                                                                                                                      \
-  FX_SB
+  FX_Q(0, 0) FX_SB FX_DMA_E(if ((TW) >= 0) pieceW(TW, 0);) FX_RD(FX_RDH_B(NXS, NTAP, 0, 0) FX_RDH_A(NWS, 0, 0)) FX_SB     \
+  FX_Q(0, 1) FX_SB FX_DMA_E(if ((TW) >= 0) pieceW(TW, 1);) FX_RD(FX_RDH_B(NXS, NTAP, 1, 0) FX_RDH_A(NWS, 1, 0)) FX_SB     \
+  FX_Q(1, 0) FX_SB FX_DMA_E(if ((TW) >= 0) pieceW(TW, 2);) FX_RD(FX_RDH_A(NWS, 2, 0) FX_RDH_A(NWS, 3, 0)) FX_SB           \
+  FX_Q(1, 1) FX_SB FX_DMA_E(if ((TW) >= 0) pieceW(TW, 3);) FX_RD(FX_RDH_B(NXS, NTAP, 0, 1) FX_RDH_B(NXS, NTAP, 1, 1)) FX_SB \
+  FX_Q(2, 0) FX_SB FX_DMA_L(if ((TW) >= 0) { pieceW(TW, 0); pieceW(TW, 1); }) FX_RD(FX_RDH_A(NWS, 0, 1) FX_RDH_A(NWS, 1, 1)) FX_SB \
+  FX_Q(2, 1) FX_SB FX_DMA_L(if ((TW) >= 0) { pieceW(TW, 2); pieceW(TW, 3); }) FX_RD(FX_RDH_A(NWS, 2, 1) FX_RDH_A(NWS, 3, 1)) FX_SB \
+  FX_Q(3, 0) FX_SB if (!(dbg & 1) && (XC) >= 0) { pieceX(XC, XP, 0); pieceX(XC, XP, 1); pieceX(XC, XP, 2); } FX_SB       \
+  FX_Q(3, 1) FX_SB if (KW == 1 && !(dbg & 1) && (XC) >= 0) { pieceX(XC, 1, 0); pieceX(XC, 1, 1); } FX_SB
 
   if (KW == 3) {
     // two chunks (six K-tiles) per iteration so that every stage index is a constant.  The next chunk's activation slabs
@@ -290,23 +301,29 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
     // previous chunk's last barrier, and it is first read behind this chunk's last one.
     for (int c = 0; c < nch; c += 2) {
       const int t = 3 * c;
-      FX_TILE(0, 0, 0, 1, 0, 1, if (t + 2 < n) issueW(t + 2); if (c + 1 < nch) issueX(c + 1, 0);)
-      FX_TILE(1, 0, 1, 0, 0, 2, if (t + 3 < n) issueW(t + 3); if (c + 1 < nch) issueX(c + 1, 1);)
-      FX_TILE(0, 0, 2, 1, 1, 0, if (t + 4 < n) issueW(t + 4);)
-      FX_TILE(1, 1, 0, 0, 1, 1, if (t + 5 < n) issueW(t + 5); if (c + 2 < nch) issueX(c + 2, 0);)
-      FX_TILE(0, 1, 1, 1, 1, 2, if (t + 6 < n) issueW(t + 6); if (c + 2 < nch) issueX(c + 2, 1);)
-      FX_TILE(1, 1, 2, 0, 0, 0, if (t + 7 < n) issueW(t + 7);)
+      const int x1 = c + 1 < nch ? c + 1 : -1, x2 = c + 2 < nch ? c + 2 : -1;
+      FX_TILE(0, 0, 0, 1, 0, 1, (t + 2 < n ? t + 2 : -1), x1, 0)
+      FX_TILE(1, 0, 1, 0, 0, 2, (t + 3 < n ? t + 3 : -1), x1, 1)
+      FX_TILE(0, 0, 2, 1, 1, 0, (t + 4 < n ? t + 4 : -1), -1, 0)
+      FX_TILE(1, 1, 0, 0, 1, 1, (t + 5 < n ? t + 5 : -1), x2, 0)
+      FX_TILE(0, 1, 1, 1, 1, 2, (t + 6 < n ? t + 6 : -1), x2, 1)
+      FX_TILE(1, 1, 2, 0, 0, 0, (t + 7 < n ? t + 7 : -1), -1, 0)
     }
   } else {
+    // width 1: a chunk is one K-tile; both planes of chunk t + 2 follow its weights (last two gaps of the tile)
     for (int t = 0; t < n; t += 2) {
-      FX_TILE(0, 0, 0, 1, 1, 0, if (t + 2 < n) { issueW(t + 2); issueX(t + 2, 0); issueX(t + 2, 1); })
-      FX_TILE(1, 1, 0, 0, 0, 0, if (t + 3 < n) { issueW(t + 3); issueX(t + 3, 0); issueX(t + 3, 1); })
+      const int a2 = t + 2 < n ? t + 2 : -1, a3 = t + 3 < n ? t + 3 : -1;
+      FX_TILE(0, 0, 0, 1, 1, 0, a2, a2, 0)
+      FX_TILE(1, 1, 0, 0, 0, 0, a3, a3, 0)
     }
   }
 #undef FX_TILE
+#undef FX_DMA_L
+#undef FX_DMA_E
+#undef FX_RD
 #undef FX_SB
-#undef FX_MMQ
-#undef FX_MMH
+#undef FX_Q
+#undef FX_H
 #undef FX_RDQ_B
 #undef FX_RDQ_A
 #undef FX_RDQ
@@ -463,7 +480,12 @@ __global__ __launch_bounds__(256) void relu_mask_fx_kernel(const u16* dy, const 
 // 2^8 -- 2^8 of headroom below fp16's 65504 for growth along the chain, 2^22 above its smallest normal -- and rearms.
 __global__ __launch_bounds__(256) void grad_amax_kernel(const float* x, long n, float* state) {
   float m = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = ((const f32x4*)x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)state + 2, __float_as_uint(m));
@@ -523,8 +545,10 @@ extern "C" int alvq_relu_mask_f16mx(const void* dy, const void* t, void* out, in
 extern "C" int alvq_grad_scale_f32(const float* x, int64_t n, float* state, void* stream) {
   ALVQ_REQUIRE(x && state, ALVQ_EINVAL, "alvq_grad_scale_f32: null pointer");
   ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_grad_scale_f32: n <= 0");
-  long gq = (n + 256 * 8 - 1) / (256 * 8);
-  if (gq > 1024) gq = 1024;
+  ALVQ_REQUIRE(((uintptr_t)x & 15) == 0, ALVQ_EINVAL, "alvq_grad_scale_f32: x must be 16-byte aligned");
+  long gq = (n / 4 + 256 * 4 - 1) / (256 * 4);
+  if (gq > 2048) gq = 2048;
+  if (gq < 1) gq = 1;
   hipLaunchKernelGGL(grad_amax_kernel, dim3((int)gq), dim3(256), 0, (hipStream_t)stream, x, (long)n, state);
   hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
   return check_launch("alvq_grad_scale_f32");

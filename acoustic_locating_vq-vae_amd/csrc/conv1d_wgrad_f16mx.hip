@@ -29,10 +29,12 @@ struct WgradFxArgs {
   int Mp, Cp, M, C;
   int mtiles, ctiles, splits, chunks_per_split, total_rows;
   int e;                 // E8M0 scale exponent of both operands (activations / scaled gradients)
+  int dbg;               // ablation switches of the DBG instantiation (ALVQ_FX_DBG, as in conv1d_f16mx.hip): 1, 2, 4, 8
 };
 
-template <int KW, int NC>      // NC = 32-column tiles per wave along c: 1 (c-tile 128, KW = 3) or 2 (c-tile 256, KW = 1)
+template <int KW, int NC, bool DBG = false>   // NC = 32-column tiles per wave along c: 1 (c-tile 128, KW = 3) or 2 (c-tile 256, KW = 1)
 __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs a) {
+  const int dbg = DBG ? a.dbg : 0;
   constexpr int PAD = (KW - 1) / 2;
   constexpr int MT = 128, CT = 4 * NC * 32;
   constexpr int YRB = MT * 2, XRB = CT * 2;
@@ -94,15 +96,19 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
 
   // ---- transposed fragment reads.  Lane l: i = l & 15 (lane of its 16-group), blk = (l >> 4) & 1 (which 16-column half
   // of the 32-wide tile), g = l >> 5 (k group of the MFMA).
-  //  fp16 (tr_b16: a 16-group reads a 4-row x 16-column block; lane 4q+p supplies row q, columns 4p..4p+3):
-  //    k-step s, group g covers the 8 rows {4G .. 4G+3} and {16+4G .. 16+4G+3}, G = 2s + g -- the same permutation of
-  //    the K-tile's rows for both operands, which a contraction does not care about; a half-wave then reads 8
-  //    consecutive rows of one 32-byte segment: conflict-free under the (row & 7) segment swizzle, for every tap.
+  //  fp16 (tr_b16: a 16-group reads a 4-row x 16-column block; lane 4q+p supplies the address of block row q, columns
+  //    4p..4p+3 -- ANY LDS row may stand for block row q):  k-step s, group g covers the 8 rows 2q + g + 8s (first
+  //    read) and 16 + 2q + g + 8s (second read), q = 0..3 -- the same permutation of the K-tile's rows for both operands,
+  //    which a contraction does not care about.  A half-wave (one g) holds two 16-column blocks, i.e. two neighbouring
+  //    32-byte segments L and L+1, times four rows: with rows of ONE parity the (row & 7) segment swizzle sends the
+  //    block-0 lanes to L ^ {g, 2+g, 4+g, 6+g} and the block-1 lanes to the complementary four segments -- 8 distinct
+  //    segments, conflict-free for every tap offset (four CONSECUTIVE rows collide two-fold: measured 33 % of the
+  //    LDS cycles in this kernel).
   //  fp8 (tr_b8: an 8-row x 16-column block; lane 2q+p supplies row q, bytes 8p..8p+7): group g covers rows 16g..16g+15
   //    in two reads, once in the hi8 segment and once in the lo8 segment of the tile's 64-byte chunk.
   const int i16 = lane & 15, blk = (lane >> 4) & 1, g = lane >> 5;
   const int q4 = i16 >> 2, p4 = i16 & 3;
-  const int krow = 4 * g + q4;                       // + 8 s for k-step s, + 16 for the second read
+  const int krow = 2 * q4 + g;                       // + 8 s for k-step s, + 16 for the second read
   const int qrow = 16 * g + (i16 >> 1);              // + 8 for the second read
   const int qbyte = 16 * blk + 8 * (i16 & 1);
   typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -169,18 +175,20 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
 #define WF_TILE(S, MORE)                                                                                           \
   /* phase 1: fp16 main term; meanwhile this K-tile's Q fragments */                                            \
   WF_MMH(0, 0) WF_SB                                                                                                \
-  WF_ALL_B(WF_RDQ_B(S, tp, cf)) WF_SB                                                                            \
+  if (!(dbg & 2)) { WF_ALL_B(WF_RDQ_B(S, tp, cf)) } WF_SB                                                        \
   WF_MMH(1, 0) WF_SB                                                                                                \
-  WF_RDQ_A(S, 0) WF_RDQ_A(S, 1) WF_SB                                                                            \
+  if (!(dbg & 2)) { WF_RDQ_A(S, 0) WF_RDQ_A(S, 1) } WF_SB                                                        \
   WF_MMH(0, 1) WF_MMH(1, 1) WF_SB                                                                                \
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
-  __builtin_amdgcn_s_barrier();                                                                                  \
+  if (!(dbg & 4)) {                                                                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                  \
+    __builtin_amdgcn_s_barrier();                                                                                \
+  }                                                                                                              \
   /* phase 2: fp8 cross terms; meanwhile the DMA of K-tile t+2 into this stage and the next tile's H fragments */ \
-  if (MORE) issue(S);                                                                                            \
+  if ((MORE) && !(dbg & 1)) issue(S);                                                                            \
   WF_MMQ(0) WF_SB                                                                                                \
-  WF_RDH_A((S) ^ 1, 0, 0) WF_RDH_A((S) ^ 1, 1, 0) WF_ALL_B(WF_RDH_B((S) ^ 1, tp, cf, 0)) WF_SB                   \
+  if (!(dbg & 2)) { WF_RDH_A((S) ^ 1, 0, 0) WF_RDH_A((S) ^ 1, 1, 0) WF_ALL_B(WF_RDH_B((S) ^ 1, tp, cf, 0)) } WF_SB \
   WF_MMQ(1) WF_SB                                                                                                \
-  WF_RDH_A((S) ^ 1, 0, 1) WF_RDH_A((S) ^ 1, 1, 1) WF_ALL_B(WF_RDH_B((S) ^ 1, tp, cf, 1)) WF_SB
+  if (!(dbg & 2)) { WF_RDH_A((S) ^ 1, 0, 1) WF_RDH_A((S) ^ 1, 1, 1) WF_ALL_B(WF_RDH_B((S) ^ 1, tp, cf, 1)) } WF_SB
 
   const bool extra = (XPIECES % 8 != 0) && (wave < XPIECES % 8);   // this wave stages one more X piece per K-tile
   if (n > 0) {
@@ -215,6 +223,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
 
   // ---- partial[split][t][m][c] = acc / loss scale (fp32); D[i = m][j = c]: lane (j = lane & 31, g), register q holds
   // m = (q & 3) + 8 (q >> 2) + 4 g
+  if (dbg & 8) {
+    if (acc[0][0][0][0] == 12345.678f) a.partial[0] = 1.f;
+    return;
+  }
   const float inv = a.inv_scale ? *a.inv_scale : 1.f;
   const int jc = lane & 31;
   float* out = a.partial + (long)split * KW * a.M * a.C;
@@ -264,14 +276,23 @@ __global__ __launch_bounds__(256) void bias_grad_fx_partial_kernel(const u16* dy
   }
 }
 
+// dbias[m] (+)= inv_scale * sum_s partial[s][m]: 32 channels x 8 split phases per workgroup (coalesced along m, 8-way
+// parallel along the splits), fixed order
 static __global__ __launch_bounds__(256) void wgrad_fx_bias_reduce_kernel(const float* bp, float* dbias, int splits, int Mp, int M,
                                                                           int accumulate, const float* inv_scale) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
+  const int mi = threadIdx.x & 31, ph = threadIdx.x >> 5;
+  const int m = blockIdx.x * 32 + mi;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += bp[(long)k * Mp + m];
-  s *= inv_scale ? *inv_scale : 1.f;
-  dbias[m] = accumulate ? dbias[m] + s : s;
+  if (m < M)
+    for (int k = ph; k < splits; k += 8) s += bp[(long)k * Mp + m];
+  __shared__ float red[8][32];
+  red[ph][mi] = s;
+  __syncthreads();
+  if (ph == 0 && m < M) {
+    float t = ((red[0][mi] + red[1][mi]) + (red[2][mi] + red[3][mi])) + ((red[4][mi] + red[5][mi]) + (red[6][mi] + red[7][mi]));
+    t *= inv_scale ? *inv_scale : 1.f;
+    dbias[m] = accumulate ? dbias[m] + t : t;
+  }
 }
 
 constexpr int FX_BIAS_SPLITS = 128;
@@ -320,16 +341,23 @@ extern "C" int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw,
   const int rows = (int)alvq_nlc_rows(B, L);
   const int ct = KW == 3 ? 128 : 256;
   WgradFxArgs a{(const u16*)dy, (const u16*)x, (float*)workspace, inv_scale, nlc_plane_elems(B, L, M), nlc_plane_elems(B, L, C),
-                pad_to(M, 64), pad_to(C, 64), M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, rows, FX_E_ACT};
+                pad_to(M, 64), pad_to(C, 64), M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, rows, FX_E_ACT, 0};
+  static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
+  a.dbg = dbg_env;
   a.splits = wgrad_fx_splits(rows, a.mtiles * a.ctiles, &a.chunks_per_split);
   float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
   static DeviceOnce attr;
   if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<3, 1>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<1, 2>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<3, 1>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<1, 2>());
   }
   const int grid = a.mtiles * a.ctiles * a.splits;
-  if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1>()), s, a);
+  if (dbg_env) {
+    if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1, true>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1>()), s, a);
+    else hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<1, 2, true>), dim3(grid), dim3(512), (wgrad_fx_lds<1, 2>()), s, a);
+  } else if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1>()), s, a);
   else hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<1, 2>), dim3(grid), dim3(512), (wgrad_fx_lds<1, 2>()), s, a);
   int rc = check_launch("alvq_conv1d_wgrad_f16mx");
   if (rc) return rc;
@@ -338,7 +366,7 @@ extern "C" int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw,
     const int rps = (rows + FX_BIAS_SPLITS - 1) / FX_BIAS_SPLITS;
     hipLaunchKernelGGL(bias_grad_fx_partial_kernel, dim3(a.Mp / 64, FX_BIAS_SPLITS), dim3(256), 0, s, (const u16*)dy, a.dy_plane, bpart,
                        rows, a.Mp, rps, a.e);
-    hipLaunchKernelGGL(wgrad_fx_bias_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, FX_BIAS_SPLITS,
+    hipLaunchKernelGGL(wgrad_fx_bias_reduce_kernel, dim3((M + 31) / 32), dim3(256), 0, s, (const float*)bpart, dbias, FX_BIAS_SPLITS,
                        a.Mp, M, accumulate, inv_scale);
   }
   return check_launch("alvq_conv1d_wgrad_f16mx/reduce");

@@ -32,15 +32,23 @@ def pmc(path):
     return agg
 
 
+def _find(d, suffix):
+    """the CSV rocprofv3 wrote under d (its -o prefix changes per round)"""
+    hits = [f for f in sorted(os.listdir(d)) if f.endswith(suffix)]
+    if not hits:
+        raise SystemExit("no *%s under %s" % (suffix, d))
+    return os.path.join(d, hits[-1])
+
+
 def main(tag, stats_dir, fetch_dir, write_dir):
-    rows = list(csv.DictReader(open(os.path.join(stats_dir, "r01_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(_find(stats_dir, "_kernel_stats.csv"))))
     with open(os.path.join(HERE, tag + "_kernel_stats.csv"), "w") as fh:
         w = csv.writer(fh)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows[:25]:
             w.writerow([r["Name"][:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-    fetch = pmc(os.path.join(fetch_dir, "r01_counter_collection.csv"))
-    write = pmc(os.path.join(write_dir, "r01_counter_collection.csv"))
+    fetch = pmc(_find(fetch_dir, "_counter_collection.csv"))
+    write = pmc(_find(write_dir, "_counter_collection.csv"))
     per_kernel, fam = {}, collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
     for k in sorted(set(fetch) | set(write)):
         f, wr = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
