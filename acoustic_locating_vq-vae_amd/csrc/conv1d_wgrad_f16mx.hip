@@ -32,21 +32,25 @@ struct WgradFxArgs {
   int dbg;               // ablation switches of the DBG instantiation (ALVQ_FX_DBG, as in conv1d_f16mx.hip): 1, 2, 4, 8
 };
 
-template <int KW, int NC, bool DBG = false>   // NC = 32-column tiles per wave along c: 1 (c-tile 128, KW = 3) or 2 (c-tile 256, KW = 1)
+// NC / MF = 32-wide tiles per wave along c / along m: (1, 2) for KW = 3 (workgroup tile 128 m x 128 c x 3 taps, 96
+// accumulator VGPRs) and (2, 4) for KW = 1 (256 m x 256 c, 128 accumulator VGPRs: the convolution's tile, at which a
+// K-tile moves 32 bytes per matrix-pipe cycle per CU through LDS-DMA; the 128 x 256 tile of the first version moved 47).
+template <int KW, int NC, int MF, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs a) {
   const int dbg = DBG ? a.dbg : 0;
   constexpr int PAD = (KW - 1) / 2;
-  constexpr int MT = 128, CT = 4 * NC * 32;
+  constexpr int MT = 2 * MF * 32, CT = 4 * NC * 32;
   constexpr int YRB = MT * 2, XRB = CT * 2;
   constexpr int XROWS = KW == 1 ? 32 : 36;
   constexpr int YBYTES = 32 * YRB, XBYTES = XROWS * XRB;
   constexpr int STAGE = 2 * YBYTES + 2 * XBYTES;      // dY.H, dY.Q, X.H, X.Q
   constexpr int XPIECES = XBYTES / 1024, XROWS_PER_PIECE = 1024 / XRB;
+  constexpr int YPIECES = YBYTES / 1024, YROWS_PER_PIECE = 1024 / YRB;     // 8 or 16 pieces per plane: 1 or 2 per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 2) * 64, wc0 = (wave & 3) * NC * 32;
+  const int wm0 = (wave >> 2) * (MF * 32), wc0 = (wave & 3) * NC * 32;
   const int ntile = a.mtiles * a.ctiles;
   const int id = xcd_remap(blockIdx.x, ntile * a.splits);
   const int split = id / ntile, t_id = id % ntile;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
   const int n = (rend - rbeg) / 32;
 
   // ---- staging: identical to the bf16x3 kernel (the Q plane has a bf16 plane's geometry: 64 bytes per 32 channels)
-  const int y_r = lane >> 4, y_s = lane & 15;
+  const int y_r = (lane * 16) / YRB, y_s = ((lane * 16) % YRB) >> 4;
   const int x_r = (lane * 16) / XRB, x_s = ((lane * 16) % XRB) >> 4;
   auto src_slot = [](int slot, int row) { return (slot & 16) | (((((slot >> 1) & 7) ^ (row & 7)) << 1) | (slot & 1)); };
   const int last_row = a.total_rows - 1;
@@ -71,12 +75,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
   int is_row = rbeg;
   auto issue = [&](int stage) {
     const unsigned dst = lds0 + stage * STAGE;
-    {
-      const int lr = 4 * wave + y_r;
+#pragma unroll
+    for (int q = 0; q < YPIECES / 8; ++q) {
+      const int p = wave + 8 * q;
+      const int lr = p * YROWS_PER_PIECE + y_r;
       const int mcol = min(m0 + src_slot(y_s, lr) * 8, a.Mp - 8);
       const unsigned off = (unsigned)(((long)(is_row + lr) * a.Mp + mcol) * 2);
-      dma(dy_h, off, dst + wave * 1024);
-      dma(dy_q, off, dst + YBYTES + wave * 1024);
+      dma(dy_h, off, dst + p * 1024);
+      dma(dy_q, off, dst + YBYTES + p * 1024);
     }
 #pragma unroll
     for (int q = 0; q < (XPIECES + 7) / 8; ++q) {
@@ -115,11 +121,22 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
   typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) i32x2* lds_tr8_ptr;
-  // byte offset of (row, 32-byte segment seg) inside a slab with ROWB-byte rows (seg may exceed 7: 256-byte lines)
-  auto seg_off = [](int row, int seg, int rowb) { return row * rowb + (seg >> 3) * 256 + (((seg & 7) ^ (row & 7)) << 5); };
+  // Byte offset of (row, 32-byte segment seg) in a slab with ROWB-byte rows: row * ROWB + (seg >> 3) * 256 +
+  // (((seg & 7) ^ (row & 7)) << 5).  The segment of fragment f of a wave is (wave part) + 2 f + (lane part) with the
+  // three parts in disjoint bits, so the XOR factors: offset = LANE BASE ^ (f << 6) (^ 32 for the lo8 segment) -- one
+  // base register per operand and tap instead of one address register per fragment.
+  const int sA = wm0 >> 4, sB = wc0 >> 4;            // first 16-column block (= 32-byte H segment) of the wave
+  const int aHb = krow * YRB + p4 * 8 + (sA >> 3) * 256 + ((((sA & 7) ^ blk) ^ (krow & 7)) << 5);
+  const int aQb = qrow * YRB + qbyte + (sA >> 3) * 256 + (((sA & 7) ^ (qrow & 7)) << 5);   // Q chunk c = segments 2c, 2c+1
+  int bHb[KW], bQb[KW];
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    bHb[t] = (krow + t) * XRB + p4 * 8 + (sB >> 3) * 256 + ((((sB & 7) ^ blk) ^ ((krow + t) & 7)) << 5);
+    bQb[t] = (qrow + t) * XRB + qbyte + (sB >> 3) * 256 + (((sB & 7) ^ ((qrow + t) & 7)) << 5);
+  }
 
-  f16x8_t aH[2][2], bH[KW][NC][2];
-  i32x8 aQ[2], bQ[KW][NC];
+  f16x8_t aH[MF][2], bH[KW][NC][2];
+  i32x8 aQ[MF], bQ[KW][NC];
 #define WF_TR16(DST, OFF, ROWB)                                                                                  \
   {                                                                                                              \
     const s16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(lds + (OFF)));                    \
@@ -135,28 +152,26 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
     const i32x2 b1_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_tr8_ptr)(lds + (SECOND) + 8 * (ROWB)));      \
     DST = i32x8{a0_[0], a0_[1], a1_[0], a1_[1], b0_[0], b0_[1], b1_[0], b1_[1]};                                \
   }
-  // A operand (dY): 16-column block index of tile mi = (wm0 >> 4) + 2 mi + blk; its 32-channel chunk = (wm0 >> 5) + mi
-#define WF_RDH_A(STAGE_, MI, KS) \
-  WF_TR16(aH[MI][KS], (STAGE_) * STAGE + seg_off(krow + 8 * (KS), (wm0 >> 4) + 2 * (MI) + blk, YRB) + p4 * 8, YRB)
-#define WF_RDQ_A(STAGE_, MI)                                                                                     \
-  WF_TR8(aQ[MI], (STAGE_) * STAGE + YBYTES + seg_off(qrow, 2 * ((wm0 >> 5) + (MI)), YRB) + qbyte,                \
-         (STAGE_) * STAGE + YBYTES + seg_off(qrow, 2 * ((wm0 >> 5) + (MI)) + 1, YRB) + qbyte, YRB)
-  // B operand (X), tap TP: rows shifted by TP; blocks are (lo8, hi8) so that block 0 pairs dY.hi8 with X.lo8
-#define WF_RDH_B(STAGE_, TP, CF, KS)                                                                             \
-  WF_TR16(bH[TP][CF][KS], (STAGE_) * STAGE + 2 * YBYTES + seg_off(krow + 8 * (KS) + (TP), (wc0 >> 4) + 2 * (CF) + blk, XRB) + p4 * 8, XRB)
-#define WF_RDQ_B(STAGE_, TP, CF)                                                                                 \
-  WF_TR8(bQ[TP][CF], (STAGE_) * STAGE + 2 * YBYTES + XBYTES + seg_off(qrow + (TP), 2 * ((wc0 >> 5) + (CF)) + 1, XRB) + qbyte, \
-         (STAGE_) * STAGE + 2 * YBYTES + XBYTES + seg_off(qrow + (TP), 2 * ((wc0 >> 5) + (CF)), XRB) + qbyte, XRB)
+  // A operand (dY), tile MI; B operand (X), tap TP, tile CF: rows shifted by TP; B's blocks are (lo8, hi8) so that block 0
+  // pairs dY.hi8 with X.lo8
+#define WF_RDH_A(STAGE_, MI, KS) WF_TR16(aH[MI][KS], (STAGE_) * STAGE + (aHb ^ ((MI) << 6)) + 8 * (KS) * YRB, YRB)
+#define WF_RDQ_A(STAGE_, MI) \
+  WF_TR8(aQ[MI], (STAGE_) * STAGE + YBYTES + (aQb ^ ((MI) << 6)), (STAGE_) * STAGE + YBYTES + (aQb ^ ((MI) << 6) ^ 32), YRB)
+#define WF_RDH_B(STAGE_, TP, CF, KS) \
+  WF_TR16(bH[TP][CF][KS], (STAGE_) * STAGE + 2 * YBYTES + (bHb[TP] ^ ((CF) << 6)) + 8 * (KS) * XRB, XRB)
+#define WF_RDQ_B(STAGE_, TP, CF)                                                                 \
+  WF_TR8(bQ[TP][CF], (STAGE_) * STAGE + 2 * YBYTES + XBYTES + (bQb[TP] ^ ((CF) << 6) ^ 32),      \
+         (STAGE_) * STAGE + 2 * YBYTES + XBYTES + (bQb[TP] ^ ((CF) << 6)), XRB)
 
   // block scales: both operands are activation-class; A blocks = (hi8, lo8), B blocks = (lo8, hi8)
   int sa = g ? a.e - FX_LO_SHIFT : a.e, sb = g ? a.e : a.e - FX_LO_SHIFT;
   asm volatile("" : "+v"(sa), "+v"(sb));   // opaque: see the convolution kernel
 
-  f32x16 acc[KW][2][NC];
+  f32x16 acc[KW][MF][NC];
 #pragma unroll
   for (int t = 0; t < KW; ++t)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
       for (int jn = 0; jn < NC; ++jn)
 #pragma unroll
@@ -172,13 +187,15 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
 #define WF_ALL_B(M_) _Pragma("unroll") for (int tp = 0; tp < KW; ++tp) _Pragma("unroll") for (int cf = 0; cf < NC; ++cf) { M_ }
 
   // one K-tile in stage S
+#define WF_ALL_A(M_) _Pragma("unroll") for (int mi = 0; mi < MF; ++mi) { M_ }
 #define WF_TILE(S, MORE)                                                                                           \
   /* phase 1: fp16 main term; meanwhile this K-tile's Q fragments */                                            \
-  WF_MMH(0, 0) WF_SB                                                                                                \
+  WF_MMH(0, 0) WF_SB                                                                                             \
   if (!(dbg & 2)) { WF_ALL_B(WF_RDQ_B(S, tp, cf)) } WF_SB                                                        \
-  WF_MMH(1, 0) WF_SB                                                                                                \
-  if (!(dbg & 2)) { WF_RDQ_A(S, 0) WF_RDQ_A(S, 1) } WF_SB                                                        \
-  WF_MMH(0, 1) WF_MMH(1, 1) WF_SB                                                                                \
+  WF_MMH(1, 0) WF_SB                                                                                             \
+  if (!(dbg & 2)) { WF_ALL_A(WF_RDQ_A(S, mi)) } WF_SB                                                            \
+  _Pragma("unroll") for (int mi = 2; mi < MF; ++mi) { WF_MMH(mi, 0) }                                            \
+  WF_ALL_A(WF_MMH(mi, 1)) WF_SB                                                                                  \
   if (!(dbg & 4)) {                                                                                              \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                  \
     __builtin_amdgcn_s_barrier();                                                                                \
@@ -186,22 +203,24 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
   /* phase 2: fp8 cross terms; meanwhile the DMA of K-tile t+2 into this stage and the next tile's H fragments */ \
   if ((MORE) && !(dbg & 1)) issue(S);                                                                            \
   WF_MMQ(0) WF_SB                                                                                                \
-  if (!(dbg & 2)) { WF_RDH_A((S) ^ 1, 0, 0) WF_RDH_A((S) ^ 1, 1, 0) WF_ALL_B(WF_RDH_B((S) ^ 1, tp, cf, 0)) } WF_SB \
+  if (!(dbg & 2)) { WF_ALL_A(WF_RDH_A((S) ^ 1, mi, 0)) WF_ALL_B(WF_RDH_B((S) ^ 1, tp, cf, 0)) } WF_SB            \
   WF_MMQ(1) WF_SB                                                                                                \
-  if (!(dbg & 2)) { WF_RDH_A((S) ^ 1, 0, 1) WF_RDH_A((S) ^ 1, 1, 1) WF_ALL_B(WF_RDH_B((S) ^ 1, tp, cf, 1)) } WF_SB
+  if (!(dbg & 2)) { WF_ALL_A(WF_RDH_A((S) ^ 1, mi, 1)) WF_ALL_B(WF_RDH_B((S) ^ 1, tp, cf, 1)) } WF_SB            \
+  _Pragma("unroll") for (int mi = 2; mi < MF; ++mi) { WF_MMQ(mi) }                                               \
+  WF_SB
 
   const bool extra = (XPIECES % 8 != 0) && (wave < XPIECES % 8);   // this wave stages one more X piece per K-tile
   if (n > 0) {
     issue(0);
     if (n > 1) issue(1);
-    if (n > 1) {
-      if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ((XPIECES + 7) / 8) + 2) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (XPIECES / 8) + 2) : "memory");
+    if (n > 1) {   // K-tile 0 landed; K-tile 1's pieces (this wave's count) may stay in flight
+      if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ((XPIECES + 7) / 8) + 2 * (YPIECES / 8)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (XPIECES / 8) + 2 * (YPIECES / 8)) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    WF_RDH_A(0, 0, 0) WF_RDH_A(0, 1, 0) WF_RDH_A(0, 0, 1) WF_RDH_A(0, 1, 1)
+    WF_ALL_A(WF_RDH_A(0, mi, 0) WF_RDH_A(0, mi, 1))
     WF_ALL_B(WF_RDH_B(0, tp, cf, 0) WF_RDH_B(0, tp, cf, 1))
     for (int t = 0; t < n; t += 2) {
       WF_TILE(0, t + 2 < n)
@@ -210,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA-result -> VALU-read wait states (asm MFMAs are invisible)
   }
 #undef WF_TILE
+#undef WF_ALL_A
 #undef WF_ALL_B
 #undef WF_SB
 #undef WF_MMQ
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
 #pragma unroll
   for (int t = 0; t < KW; ++t)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MF; ++mi)
 #pragma unroll
       for (int cf = 0; cf < NC; ++cf)
 #pragma unroll
@@ -297,9 +317,9 @@ static __global__ __launch_bounds__(256) void wgrad_fx_bias_reduce_kernel(const 
 
 constexpr int FX_BIAS_SPLITS = 128;
 
-template <int KW, int NC>
+template <int KW, int NC, int MF>
 static constexpr int wgrad_fx_lds() {
-  return 2 * (2 * 32 * 256 + 2 * (KW == 1 ? 32 : 36) * (4 * NC * 32 * 2));
+  return 2 * (2 * 32 * (2 * MF * 32 * 2) + 2 * (KW == 1 ? 32 : 36) * (4 * NC * 32 * 2));
 }
 
 static int wgrad_fx_splits(int total_rows, int tiles, int* chunks_per_split) {
@@ -327,7 +347,8 @@ extern "C" int64_t alvq_conv1d_wgrad_f16mx_workspace_bytes(int B, int C, int M, 
   const int rows = (int)alvq_nlc_rows(B, L);
   const int ct = KW == 3 ? 128 : 256;
   int cps;
-  const int splits = wgrad_fx_splits(rows, ((M + 127) / 128) * ((C + ct - 1) / ct), &cps);
+  const int mt = KW == 3 ? 128 : 256;
+  const int splits = wgrad_fx_splits(rows, ((M + mt - 1) / mt) * ((C + ct - 1) / ct), &cps);
   return (int64_t)splits * KW * M * C * 4 + (int64_t)FX_BIAS_SPLITS * pad_to(M, 64) * 4;
 }
 
@@ -339,26 +360,26 @@ extern "C" int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw,
   ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx: w_layout");
   hipStream_t s = (hipStream_t)stream;
   const int rows = (int)alvq_nlc_rows(B, L);
-  const int ct = KW == 3 ? 128 : 256;
+  const int ct = KW == 3 ? 128 : 256, mt = KW == 3 ? 128 : 256;
   WgradFxArgs a{(const u16*)dy, (const u16*)x, (float*)workspace, inv_scale, nlc_plane_elems(B, L, M), nlc_plane_elems(B, L, C),
-                pad_to(M, 64), pad_to(C, 64), M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, rows, FX_E_ACT, 0};
+                pad_to(M, 64), pad_to(C, 64), M, C, (M + mt - 1) / mt, (C + ct - 1) / ct, 0, 0, rows, FX_E_ACT, 0};
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
   a.dbg = dbg_env;
   a.splits = wgrad_fx_splits(rows, a.mtiles * a.ctiles, &a.chunks_per_split);
   float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
   static DeviceOnce attr;
   if (attr.need()) {
-    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<3, 1>());
-    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<1, 2>());
-    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<3, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<3, 1>());
-    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<1, 2>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<3, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<3, 1, 2>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<1, 2, 4>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<3, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<3, 1, 2>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<1, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<1, 2, 4>());
   }
   const int grid = a.mtiles * a.ctiles * a.splits;
   if (dbg_env) {
-    if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1, true>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1>()), s, a);
-    else hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<1, 2, true>), dim3(grid), dim3(512), (wgrad_fx_lds<1, 2>()), s, a);
-  } else if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1>()), s, a);
-  else hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<1, 2>), dim3(grid), dim3(512), (wgrad_fx_lds<1, 2>()), s, a);
+    if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1, 2, true>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1, 2>()), s, a);
+    else hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<1, 2, 4, true>), dim3(grid), dim3(512), (wgrad_fx_lds<1, 2, 4>()), s, a);
+  } else if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1, 2>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1, 2>()), s, a);
+  else hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<1, 2, 4>), dim3(grid), dim3(512), (wgrad_fx_lds<1, 2, 4>()), s, a);
   int rc = check_launch("alvq_conv1d_wgrad_f16mx");
   if (rc) return rc;
   wgrad_reduce_launch((const float*)workspace, dw, a.splits, KW, M, C, w_layout, accumulate, s);
