@@ -20,9 +20,15 @@
 
 namespace alvq {
 
+constexpr int WF_MAXSEG = 4;
 struct WgradFxArgs {
-  const u16* dy;
-  const u16* x;
+  // Up to WF_MAXSEG (dy, x) pairs of identical shape whose products are summed into ONE dW: the R uses of a shared
+  // residual weight (residual_stack.py:40-41) become a single longer contraction -- one split reduction instead of R.
+  // Rows are numbered through all segments: virtual row v = seg * total_rows + r (total_rows % 64 == 0, so neither a
+  // 64-row chunk nor a 32-row K-tile straddles two segments).
+  const u16* dy[WF_MAXSEG];
+  const u16* x[WF_MAXSEG];
+  int nseg;
   float* partial;        // [splits][KW][M][C]
   const float* inv_scale;   // device scalar multiplied into every partial (1 / loss scale), or null
   long dy_plane, x_plane;
@@ -55,8 +61,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
   const int id = xcd_remap(blockIdx.x, ntile * a.splits);
   const int split = id / ntile, t_id = id % ntile;
   const int m0 = (t_id / a.ctiles) * MT, c0 = (t_id % a.ctiles) * CT;
+  const int vrows = a.nseg * a.total_rows;
   const int rbeg = split * a.chunks_per_split * 64;
-  const int rend = min(a.total_rows, rbeg + a.chunks_per_split * 64);
+  const int rend = min(vrows, rbeg + a.chunks_per_split * 64);
   const int n = (rend - rbeg) / 32;
 
   // ---- staging: identical to the bf16x3 kernel (the Q plane has a bf16 plane's geometry: 64 bytes per 32 channels)
@@ -68,13 +75,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
   auto dma = [&](const char* sbase, unsigned voff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
   };
-  const char* const dy_h = (const char*)a.dy;
-  const char* const dy_q = (const char*)(a.dy + a.dy_plane);
-  const char* const x_h = (const char*)a.x;
-  const char* const x_q = (const char*)(a.x + a.x_plane);
-  int is_row = rbeg;
+  int is_seg = rbeg / a.total_rows;          // segment and first row (inside it) of the K-tile the next issue() stages
+  int is_row = rbeg - is_seg * a.total_rows;
   auto issue = [&](int stage) {
     const unsigned dst = lds0 + stage * STAGE;
+    const char* const dy_h = (const char*)a.dy[is_seg];
+    const char* const dy_q = (const char*)(a.dy[is_seg] + a.dy_plane);
+    const char* const x_h = (const char*)a.x[is_seg];
+    const char* const x_q = (const char*)(a.x[is_seg] + a.x_plane);
 #pragma unroll
     for (int q = 0; q < YPIECES / 8; ++q) {
       const int p = wave + 8 * q;
@@ -98,6 +106,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_f16mx_kernel(WgradFxArgs 
       }
     }
     is_row += 32;
+    if (is_row == a.total_rows) {
+      is_row = 0;
+      ++is_seg;
+    }
   };
 
   // ---- transposed fragment reads.  Lane l: i = l & 15 (lane of its 16-group), blk = (l >> 4) & 1 (which 16-column half
@@ -348,24 +360,33 @@ extern "C" int64_t alvq_conv1d_wgrad_f16mx_workspace_bytes(int B, int C, int M, 
   const int ct = KW == 3 ? 128 : 256;
   int cps;
   const int mt = KW == 3 ? 128 : 256;
-  const int splits = wgrad_fx_splits(rows, ((M + mt - 1) / mt) * ((C + ct - 1) / ct), &cps);
+  const int tiles = ((M + mt - 1) / mt) * ((C + ct - 1) / ct);
+  int splits = wgrad_fx_splits(rows, tiles, &cps);
+  const int splits_multi = wgrad_fx_splits(WF_MAXSEG * rows, tiles, &cps);   // the split count never exceeds this
+  if (splits_multi > splits) splits = splits_multi;
   return (int64_t)splits * KW * M * C * 4 + (int64_t)FX_BIAS_SPLITS * pad_to(M, 64) * 4;
 }
 
-extern "C" int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C, int M,
-                                       int L, int KW, int w_layout, int accumulate, const float* inv_scale, void* stream) {
-  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx: null pointer");
-  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx: bad dims");
-  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16mx: KW=%d (only 1 and 3)", KW);
-  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx: w_layout");
-  hipStream_t s = (hipStream_t)stream;
+static int wgrad_fx_launch(const void* const* dy, const void* const* x, int nseg, float* dw, float* dbias, void* workspace, int B,
+                           int C, int M, int L, int KW, int w_layout, int accumulate, const float* inv_scale, hipStream_t s) {
   const int rows = (int)alvq_nlc_rows(B, L);
   const int ct = KW == 3 ? 128 : 256, mt = KW == 3 ? 128 : 256;
-  WgradFxArgs a{(const u16*)dy, (const u16*)x, (float*)workspace, inv_scale, nlc_plane_elems(B, L, M), nlc_plane_elems(B, L, C),
-                pad_to(M, 64), pad_to(C, 64), M, C, (M + mt - 1) / mt, (C + ct - 1) / ct, 0, 0, rows, FX_E_ACT, 0};
+  WgradFxArgs a{};
+  for (int i = 0; i < WF_MAXSEG; ++i) {
+    a.dy[i] = (const u16*)dy[i < nseg ? i : 0];
+    a.x[i] = (const u16*)x[i < nseg ? i : 0];
+  }
+  a.nseg = nseg;
+  a.partial = (float*)workspace;
+  a.inv_scale = inv_scale;
+  a.dy_plane = nlc_plane_elems(B, L, M);
+  a.x_plane = nlc_plane_elems(B, L, C);
+  a.Mp = pad_to(M, 64); a.Cp = pad_to(C, 64); a.M = M; a.C = C;
+  a.mtiles = (M + mt - 1) / mt; a.ctiles = (C + ct - 1) / ct;
+  a.total_rows = rows; a.e = FX_E_ACT;
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
   a.dbg = dbg_env;
-  a.splits = wgrad_fx_splits(rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  a.splits = wgrad_fx_splits(nseg * rows, a.mtiles * a.ctiles, &a.chunks_per_split);
   float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
   static DeviceOnce attr;
   if (attr.need()) {
@@ -383,12 +404,33 @@ extern "C" int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw,
   int rc = check_launch("alvq_conv1d_wgrad_f16mx");
   if (rc) return rc;
   wgrad_reduce_launch((const float*)workspace, dw, a.splits, KW, M, C, w_layout, accumulate, s);
-  if (dbias) {
+  if (dbias) {     // single segment only (the shared residual weights have no bias)
     const int rps = (rows + FX_BIAS_SPLITS - 1) / FX_BIAS_SPLITS;
-    hipLaunchKernelGGL(bias_grad_fx_partial_kernel, dim3(a.Mp / 64, FX_BIAS_SPLITS), dim3(256), 0, s, (const u16*)dy, a.dy_plane, bpart,
+    hipLaunchKernelGGL(bias_grad_fx_partial_kernel, dim3(a.Mp / 64, FX_BIAS_SPLITS), dim3(256), 0, s, (const u16*)dy[0], a.dy_plane, bpart,
                        rows, a.Mp, rps, a.e);
     hipLaunchKernelGGL(wgrad_fx_bias_reduce_kernel, dim3((M + 31) / 32), dim3(256), 0, s, (const float*)bpart, dbias, FX_BIAS_SPLITS,
                        a.Mp, M, accumulate, inv_scale);
   }
   return check_launch("alvq_conv1d_wgrad_f16mx/reduce");
+}
+
+extern "C" int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C, int M,
+                                       int L, int KW, int w_layout, int accumulate, const float* inv_scale, void* stream) {
+  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16mx: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx: w_layout");
+  return wgrad_fx_launch(&dy, &x, 1, dw, dbias, workspace, B, C, M, L, KW, w_layout, accumulate, inv_scale, (hipStream_t)stream);
+}
+
+extern "C" int alvq_conv1d_wgrad_f16mx_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                             int B, int C, int M, int L, int KW, int w_layout, int accumulate,
+                                             const float* inv_scale, void* stream) {
+  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx_multi: null pointer");
+  ALVQ_REQUIRE(nseg >= 1 && nseg <= WF_MAXSEG, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16mx_multi: nseg=%d (1..4)", nseg);
+  for (int i = 0; i < nseg; ++i) ALVQ_REQUIRE(dy[i] && x[i], ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx_multi: null segment %d", i);
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx_multi: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16mx_multi: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx_multi: w_layout");
+  return wgrad_fx_launch(dy, x, nseg, dw, nullptr, workspace, B, C, M, L, KW, w_layout, accumulate, inv_scale, (hipStream_t)stream);
 }

@@ -272,7 +272,7 @@ class _BF16Engine:
 
     @property
     def wgrad_multi(self):
-        """sum_i wgrad(dy_i, x_i) in one launch -- plain bf16 only (the split mode loops)."""
+        """sum_i wgrad(dy_i, x_i) in one launch -- bf16 and f16mx (the split-bf16 mode loops)."""
         return N.conv1d_wgrad_bf16_multi if self.planes == 1 else None
 
     def pack(self, act):
@@ -301,7 +301,7 @@ class _F16MXEngine(_BF16Engine):
 
     @property
     def wgrad_multi(self):
-        return None
+        return N.conv1d_wgrad_bf16_multi
 
 
 _ENGINES = {"f32": _F32Engine, "bf16": _BF16Engine, "bf16x3": _BF16x3Engine, "f16mx": _F16MXEngine}

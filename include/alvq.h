@@ -296,6 +296,11 @@ int64_t alvq_conv1d_wgrad_f16mx_workspace_bytes(int B, int C, int M, int L, int 
 int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
                             int B, int C, int M, int L, int KW, int w_layout, int accumulate,
                             const float* inv_scale, void* stream);
+/* dw (+)= inv_scale * sum_i wgrad(dy[i], x[i]) over nseg (1..4) pairs of one shape in ONE launch (the R uses of a shared
+ * residual weight), as alvq_conv1d_wgrad_bf16_multi; all segments carry the same loss scale. */
+int alvq_conv1d_wgrad_f16mx_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                  int B, int C, int M, int L, int KW, int w_layout, int accumulate,
+                                  const float* inv_scale, void* stream);
 
 /* ================================================================================================
  * Location head: LocationModule.fc_1 = nn.Linear(L*K, M) on the flattened one-hot codes of a

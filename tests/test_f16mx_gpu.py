@@ -103,6 +103,34 @@ def test_wgrad_f16mx_matches_fp32(B, C, M, L, KW):
     assert rel(N.conv1d_wgrad_bf16(dyn, xn, KW, N.W_IOK), wt.grad) < KERNEL
 
 
+@pytest.mark.parametrize("KW", [1, 3])
+@pytest.mark.parametrize("nseg", [1, 2, 3, 4])
+def test_wgrad_f16mx_multi_sums_the_uses_of_a_shared_weight(nseg, KW):
+    """One launch over nseg (dy, x) pairs == the sum of nseg single launches (residual_stack.py:40-41 shares one weight
+    between the R layers); a loss scale common to the chain is divided out once; accumulate adds to what dw held."""
+    torch.manual_seed(6)
+    B, C, M, L = 3, 72, 136, 95
+    mag = 1e-6
+    xs = [torch.randn(B, C, L) for _ in range(nseg)]
+    dys = [torch.randn(B, M, L) * mag for _ in range(nseg)]
+    w = (torch.randn(M, C, KW) / (C * KW) ** 0.5).requires_grad_(True)
+    for x, dy in zip(xs, dys):
+        F.conv1d(x, w, None, padding=KW // 2).backward(dy)
+    state = N.grad_scale(torch.stack(dys).cuda())
+    pairs = [(fx(dy, state), fx(x)) for dy, x in zip(dys, xs)]
+    dw = N.conv1d_wgrad_bf16_multi(pairs, KW, N.W_OIK)
+    assert rel(dw, w.grad) < KERNEL
+    singles = sum(N.conv1d_wgrad_bf16(dy, x, KW, N.W_OIK) for dy, x in pairs)
+    assert rel(dw, singles) < 1e-6
+    base = torch.randn(M, C, KW, device="cuda") * mag
+    acc = N.conv1d_wgrad_bf16_multi(pairs, KW, N.W_OIK, dw_out=base.clone(), accumulate=True)
+    assert rel(acc, base.cpu() + w.grad) < KERNEL
+    other = N.grad_scale(dys[0].cuda())
+    if nseg > 1:
+        with pytest.raises(RuntimeError, match="loss-scale"):
+            N.conv1d_wgrad_bf16_multi([pairs[0], (fx(dys[1], other), pairs[1][1])], KW)
+
+
 @pytest.mark.parametrize("mag", [1e-9, 3e-5, 1.0, 4e4])
 def test_loss_scale_carries_gradients_of_any_magnitude(mag):
     """A gradient chain enters the format multiplied by a power of two chosen on the device from its amax and leaves it
