@@ -545,7 +545,15 @@ static __global__ __launch_bounds__(256) void wgrad_x3_bias_reduce_kernel(const 
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += bp[(long)k * Mp + m];
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {      // eight loads in flight (one at a time is a round trip to L2 per split)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bp[(long)(k + j) * Mp + m];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; k < splits; ++k) s += bp[(long)k * Mp + m];
   dbias[m] = accumulate ? dbias[m] + s : s;
 }
 

@@ -128,7 +128,7 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   }
 }
 
-template <int OUT, int KW, bool DBG = false>
+template <int OUT, int KW, int DBG = 0>   // DBG: 1 run-time ablation switches, 2 also no fp16 MFMAs, 3 also no fp8 MFMAs
 __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   constexpr int PAD = (KW - 1) / 2;
   const int dbg = DBG ? ax.dbg : 0;
@@ -236,10 +236,17 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
-#define FX_H(MI, NI, KS) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[MI][NI]) : "v"(aH[MI][KS]), "v"(bH[NI][KS]));
-#define FX_Q(MI, NI)                                                                       \
-  asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"         \
-      : "+v"(acc[MI][NI]) : "v"(aQ[MI]), "v"(bQ[NI]), "v"(sa), "v"(sb));
+#define FX_H(MI, NI, KS) if (DBG != 2) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[MI][NI]) : "v"(aH[MI][KS]), "v"(bH[NI][KS]));
+#define FX_Q(MI, NI)                                                                          \
+  if (DBG == 4) {   /* timing probe: the same operands read as fp6 (e2m3), half the pipe cycles */ \
+    typedef int i32x6 __attribute__((ext_vector_type(6)));                                      \
+    const i32x6 a6_ = __builtin_shufflevector(aQ[MI], aQ[MI], 0, 1, 2, 3, 4, 5);                \
+    const i32x6 b6_ = __builtin_shufflevector(bQ[NI], bQ[NI], 0, 1, 2, 3, 4, 5);                \
+    asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" \
+        : "+v"(acc[MI][NI]) : "v"(a6_), "v"(b6_), "v"(sa), "v"(sb));                            \
+  } else if (DBG != 3)                                                                          \
+    asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"            \
+        : "+v"(acc[MI][NI]) : "v"(aQ[MI]), "v"(bQ[NI]), "v"(sa), "v"(sb));
 #define FX_SB __builtin_amdgcn_sched_barrier(0);
 
   const int nch = Cp / FX_K;        // chunks; even (Cp % 64 == 0)
@@ -480,15 +487,30 @@ __global__ __launch_bounds__(256) void relu_mask_fx_kernel(const u16* dy, const 
 // 2^8 -- 2^8 of headroom below fp16's 65504 for growth along the chain, 2^22 above its smallest normal -- and rearms.
 __global__ __launch_bounds__(256) void grad_amax_kernel(const float* x, long n, float* state) {
   float m = 0.f;
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+  const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {      // four independent 16-byte loads in flight per thread
+    const f32x4 a = ((const f32x4*)x)[i], b = ((const f32x4*)x)[i + stride], c = ((const f32x4*)x)[i + 2 * stride],
+                d = ((const f32x4*)x)[i + 3 * stride];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = fmaxf(fmaxf(m, fmaxf(fabsf(a[k]), fabsf(b[k]))), fmaxf(fabsf(c[k]), fabsf(d[k])));
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = ((const f32x4*)x)[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
   }
-  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  for (long j = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) m = fmaxf(m, fabsf(x[j]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)state + 2, __float_as_uint(m));
+  // one atomic per workgroup (thousands of same-address atomics serialise at the L2: they, not the 26 MB read, set the
+  // 51 us this pass took with one atomic per wave on 2048 workgroups)
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    if (m > 0.f) atomicMax((unsigned*)state + 2, __float_as_uint(m));
+  }
 }
 __global__ void grad_scale_kernel(float* state) {
   const unsigned bits = ((unsigned*)state)[2];
@@ -547,7 +569,7 @@ extern "C" int alvq_grad_scale_f32(const float* x, int64_t n, float* state, void
   ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_grad_scale_f32: n <= 0");
   ALVQ_REQUIRE(((uintptr_t)x & 15) == 0, ALVQ_EINVAL, "alvq_grad_scale_f32: x must be 16-byte aligned");
   long gq = (n / 4 + 256 * 4 - 1) / (256 * 4);
-  if (gq > 2048) gq = 2048;
+  if (gq > 512) gq = 512;
   if (gq < 1) gq = 1;
   hipLaunchKernelGGL(grad_amax_kernel, dim3((int)gq), dim3(256), 0, (hipStream_t)stream, x, (long)n, state);
   hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
@@ -580,13 +602,19 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
-    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
-    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
   }
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
   if (dbg_env && y) {
-    if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, true>), grid, block, FX_LDS, s, a);
-    else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, true>), grid, block, FX_LDS, s, a);
+    if (KW == 3 && (dbg_env & 16)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 2>), grid, block, FX_LDS, s, a);
+    else if (KW == 3 && (dbg_env & 32)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 3>), grid, block, FX_LDS, s, a);
+    else if (KW == 3 && (dbg_env & 64)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 4>), grid, block, FX_LDS, s, a);
+    else if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 1>), grid, block, FX_LDS, s, a);
+    else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, 1>), grid, block, FX_LDS, s, a);
     return check_launch("alvq_conv1d_f16mx(dbg)");
   }
   if (y) {

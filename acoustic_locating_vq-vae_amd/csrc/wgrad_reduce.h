@@ -24,7 +24,13 @@ static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int 
     }
     const long src = ((long)t * M + m) * C + c;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partial[(long)k * total + src];
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {    // four loads in flight; same summation order as one at a time
+      const float v0 = partial[(long)k * total + src], v1 = partial[(long)(k + 1) * total + src],
+                  v2 = partial[(long)(k + 2) * total + src], v3 = partial[(long)(k + 3) * total + src];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; k < splits; ++k) s += partial[(long)k * total + src];
     dw[e] = accumulate ? dw[e] + s : s;
   }
 }

@@ -24,8 +24,8 @@ def timeit(fn, iters=10, warm=3):
 
 
 def main():
-    B, L = 64, 500
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    B, L = (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 500      # B=4 fills 32 of the 256 CUs: the un-throttled rate
     for (C, M, KW) in [(1024, 1024, 3), (1024, 1024, 1), (201, 1024, 3), (1024, 201, 3), (1024, 128, 3)]:
         flops = 2.0 * B * L * M * C * KW
         x = torch.randn(B, C, L, device="cuda")
