@@ -66,6 +66,7 @@ __device__ __forceinline__ void fx_store16(u16* p, long plane, long row_elems, i
 // of four.  Two rounds of v_permlane32_swap (groups 0 <-> 2, then 1 <-> 3) give the lane 16 CONSECUTIVE channels
 // (16 h .. 16 h + 15 of the tile), so every load and store is 16 bytes and the two lanes of a row cover one whole 64-byte
 // H segment and one whole 64-byte Q chunk.
+template <int NIN>
 __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32x16 (&acc)[4][2], int m0, int r0, int lane, int wm0,
                                                  int wn0) {
   const ConvBArgs& a = ax.b;
@@ -73,7 +74,7 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   const float s_lo = fx_pow2(ax.eb - FX_LO_SHIFT), s_hi = fx_pow2(ax.eb);
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
+  for (int ni = 0; ni < NIN; ++ni) {
     const int row = r0 + wn0 + ni * 32 + j;
     int b, l;
     const bool ok = row_valid(row, Lp1, ndata, &b, &l);
@@ -128,19 +129,24 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   }
 }
 
-template <int OUT, int KW, int DBG = 0>   // DBG: 1 run-time ablation switches, 2 also no fp16 MFMAs, 3 also no fp8 MFMAs
+// DBG: 1 run-time ablation switches, 2 also no fp16 MFMAs, 3 also no fp8 MFMAs, 4 the fp8 MFMAs issued as fp6.
+// NIN: 32-row blocks per wave.  2 = the 256-row tile; 1 = a 128-row tile (a wave owns 128 x 32) for launches whose 256-row
+// grid would leave CUs idle (one m-tile: M <= 256, or few rows) -- twice the workgroups at 5/4 instead of 6/8 fragment
+// reads per MFMA.
+template <int OUT, int KW, int DBG = 0, int NIN = 2>
 __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   constexpr int PAD = (KW - 1) / 2;
+  constexpr int RT = 128 * NIN;          // rows per workgroup
   const int dbg = DBG ? ax.dbg : 0;
   const ConvBArgs& a = ax.b;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 32 * NIN;
 
   const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
   const int m0 = (tile % a.mtiles) * FX_M;
-  const int r0 = (tile / a.mtiles) * FX_R;
+  const int r0 = (tile / a.mtiles) * RT;
   const int Cp = a.Cp;
 
   // ---- DMA (a piece is 16 rows x 64 B; lane i -> row i>>2, slot i&3 <- 16-byte group (i&3) ^ h[(row>>2)&3] of the
@@ -180,8 +186,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   auto pieceX = [&](int chunk, int plane, int k) {
     const unsigned dst = lds0 + XBASE + (chunk & 1) * FX_XSTAGE + plane * FX_XSLAB + wave * 2048;
     const char* xs = xb + plane * xpl + chunk * (FX_K * 2);
+    if (wave * 32 >= RT) return;          // 128-row tile: waves 0-3 stage the activation rows
     if (k < 2) dma(xs + k * row16, dst + k * 1024);
-    else if (KW == 3 && wave == 7 && srow < 2) dma(xs + 2 * row16, dst + 2048);
+    else if (KW == 3 && wave == RT / 32 - 1 && srow < 2) dma(xs + 2 * row16, dst + 2048);
   };
   auto issueX = [&](int chunk, int plane) {
     pieceX(chunk, plane, 0);
@@ -214,14 +221,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   f16x8_t aH[4][2], bH[2][2];
   i32x8 aQ[4], bQ[2];
 #define FX_RDH_A(WS, MI, KS) aH[MI][KS] = *(const f16x8_t*)(abase + (WS) * FX_WSTAGE + (MI) * 2048 + offA[KS]);
-#define FX_RDH_B(XS, TAP, NI, KS) bH[NI][KS] = *(const f16x8_t*)(bbase + (XS) * FX_XSTAGE + (NI) * 2048 + offB[TAP][KS]);
+#define FX_RDH_B(XS, TAP, NI, KS) if ((NI) < NIN) bH[NI][KS] = *(const f16x8_t*)(bbase + (XS) * FX_XSTAGE + (NI) * 2048 + offB[TAP][KS]);
 #define FX_RDQ(DST, P, FIRST, SECOND)                                                           \
   {                                                                                             \
     const i32x4 q0_ = *(const i32x4*)((P) + (FIRST)), q1_ = *(const i32x4*)((P) + (SECOND));    \
     DST = __builtin_shufflevector(q0_, q1_, 0, 1, 2, 3, 4, 5, 6, 7);                            \
   }
 #define FX_RDQ_A(WS, MI) FX_RDQ(aQ[MI], abase + (WS) * FX_WSTAGE + FX_SLAB + (MI) * 2048, offA[0], offA[1])
-#define FX_RDQ_B(XS, TAP, NI) FX_RDQ(bQ[NI], bbase + (XS) * FX_XSTAGE + FX_XSLAB + (NI) * 2048, offB[TAP][1], offB[TAP][0])
+#define FX_RDQ_B(XS, TAP, NI) if ((NI) < NIN) FX_RDQ(bQ[NI], bbase + (XS) * FX_XSTAGE + FX_XSLAB + (NI) * 2048, offB[TAP][1], offB[TAP][0])
 
   // block scales of the fp8 MFMA: lanes 0-31 supply block 0, lanes 32-63 block 1.  Opaque to the compiler so that it keeps
   // them in registers instead of re-materialising them by VALU moves in front of the inline-asm MFMAs (no hazard padding
@@ -236,9 +243,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
-#define FX_H(MI, NI, KS) if (DBG != 2) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[MI][NI]) : "v"(aH[MI][KS]), "v"(bH[NI][KS]));
+#define FX_H(MI, NI, KS) if (DBG != 2 && (NI) < NIN) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[MI][NI]) : "v"(aH[MI][KS]), "v"(bH[NI][KS]));
 #define FX_Q(MI, NI)                                                                          \
-  if (DBG == 4) {   /* timing probe: the same operands read as fp6 (e2m3), half the pipe cycles */ \
+  if ((NI) >= NIN) {                                                                            \
+  } else if (DBG == 4) {   /* timing probe: the same operands read as fp6 (e2m3), half the pipe cycles */ \
     typedef int i32x6 __attribute__((ext_vector_type(6)));                                      \
     const i32x6 a6_ = __builtin_shufflevector(aQ[MI], aQ[MI], 0, 1, 2, 3, 4, 5);                \
     const i32x6 b6_ = __builtin_shufflevector(bQ[NI], bQ[NI], 0, 1, 2, 3, 4, 5);                \
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) { FX_RDH_A(0, mi, 0) FX_RDH_A(0, mi, 1) }
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) { FX_RDH_B(0, 0, ni, 0) FX_RDH_B(0, 0, ni, 1) }
+  for (int ni = 0; ni < NIN; ++ni) { FX_RDH_B(0, 0, ni, 0) FX_RDH_B(0, 0, ni, 1) }
 
   // One K-tile: weights in stage WS, activations in stage XS read at tap TAP; the next K-tile's are (NWS, NXS, NTAP).
   // TW = the K-tile whose weights are staged behind this tile's barrier (into the weight stage this tile occupied), or
@@ -344,23 +352,23 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
     return;
   }
   if (OUT == 0) {
-    wave_epilogue_fx(ax, acc, m0, r0, lane, wm0, wn0);
+    wave_epilogue_fx<NIN>(ax, acc, m0, r0, lane, wm0, wn0);
     return;
   }
   __syncthreads();   // the C slab overlays the stages: the trailing fragment reads of every wave must be done
-  // ---- OUT == 1 (fp32 NCL, bias only, optional output scale): four 64-row slabs through an fp32 LDS tile
+  // ---- OUT == 1 (fp32 NCL, bias only, optional output scale): 64-row slabs through an fp32 LDS tile
   float* Cs = (float*)lds;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   const float oscale = ax.out_scale ? *ax.out_scale : 1.f;
-  for (int slab = 0; slab < 4; ++slab) {
-    if ((wave & 3) == slab) {
+  for (int slab = 0; slab < RT / 64; ++slab) {
+    if ((wn0 >> 6) == slab) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NIN; ++ni)
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) {
-            const int rl = ni * 32 + r32, ml = wm0 + mi * 32 + 8 * q4 + 4 * g;
+            const int rl = (wn0 & 63) + ni * 32 + r32, ml = wm0 + mi * 32 + 8 * q4 + 4 * g;
             *(f32x4*)(Cs + rl * FX_CS + ml) =
                 f32x4{acc[mi][ni][4 * q4], acc[mi][ni][4 * q4 + 1], acc[mi][ni][4 * q4 + 2], acc[mi][ni][4 * q4 + 3]};
           }
@@ -590,7 +598,7 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
   const long rows = alvq_nlc_rows(B, L);
   ConvFxArgs a{{(const u16*)x, (const u16*)wp, bias, (const u16*)skip1, (const u16*)skip2, (const u16*)mask, (const u16*)post,
                 (u16*)y, (u16*)y2, y_ncl, B, L, pad_to(C, 64), M, pad_to(M, 64), pad_to(M, WP_ROWS), relu ? 1 : 0,
-                (int)(rows / FX_R), pad_to(M, FX_M) / FX_M},
+                (int)(rows / FX_R), pad_to(M, FX_M) / FX_M},   /* rtiles: see below */
                nlc_plane_elems(B, L, C), (long)alvq_packed_weight_elems(M, C, KW), nlc_plane_elems(B, L, M),
                FX_E_W, FX_E_ACT, out_scale, 0};
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
@@ -602,12 +610,22 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
   }
+  // fewer than ~3/4 of the CUs covered by 256-row tiles (one m-tile: M <= 256; short batches): 128-row tiles
+  // (ALVQ_FX_ROWS=128|256 forces one of the two -- the tests run every shape through both)
+  const char* force = getenv("ALVQ_FX_ROWS");
+  const int forced = force ? atoi(force) : 0;
+  const bool half = !dbg_env && (forced == 128 || (forced != 256 && a.b.rtiles * a.b.mtiles < 192));
+  if (half) a.b.rtiles = (int)(rows / 128);
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
   if (dbg_env && y) {
     if (KW == 3 && (dbg_env & 16)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 2>), grid, block, FX_LDS, s, a);
@@ -617,7 +635,15 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
     else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, 1>), grid, block, FX_LDS, s, a);
     return check_launch("alvq_conv1d_f16mx(dbg)");
   }
-  if (y) {
+  if (half) {
+    if (y) {
+      if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 0, 1>), grid, block, FX_LDS, s, a);
+      else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, 0, 1>), grid, block, FX_LDS, s, a);
+    } else {
+      if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<1, 3, 0, 1>), grid, block, FX_LDS, s, a);
+      else hipLaunchKernelGGL((conv1d_f16mx_kernel<1, 1, 0, 1>), grid, block, FX_LDS, s, a);
+    }
+  } else if (y) {
     if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3>), grid, block, FX_LDS, s, a);
     else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1>), grid, block, FX_LDS, s, a);
   } else {

@@ -33,6 +33,13 @@ def _mode():
     _ops.set_compute_dtype("f32")
 
 
+@pytest.fixture(params=["128", "256"])
+def rows_tile(request, monkeypatch):
+    """Both row tiles of conv1d_f16mx_kernel (256 rows per workgroup; 128 for launches that would leave CUs idle)."""
+    monkeypatch.setenv("ALVQ_FX_ROWS", request.param)
+    return request.param
+
+
 SHAPES = [(2, 7, 16, 13, 3), (2, 16, 7, 13, 3), (2, 8, 16, 13, 1), (3, 5, 1, 201, 3), (2, 201, 1024, 500, 3),
           (2, 1024, 128, 500, 3), (2, 1024, 1024, 201, 1), (2, 500, 1024, 201, 3), (2, 1024, 201, 500, 3),
           (5, 130, 130, 129, 3)]
@@ -55,7 +62,7 @@ def test_split_roundtrip_and_planes():
 
 
 @pytest.mark.parametrize("B,C,M,L,KW", SHAPES)
-def test_conv_f16mx_matches_fp32(B, C, M, L, KW):
+def test_conv_f16mx_matches_fp32(B, C, M, L, KW, rows_tile):
     torch.manual_seed(1)
     x, b = torch.randn(B, C, L), torch.randn(M)
     w = torch.randn(M, C, KW) / (C * KW) ** 0.5
@@ -70,7 +77,7 @@ def test_conv_f16mx_matches_fp32(B, C, M, L, KW):
     assert rel(N.conv1d_bf16(xn, N.pack_weight(wt.cuda(), N.W_IOK, planes=3), b.cuda(), out_ncl=True), reft) < KERNEL
 
 
-def test_conv_f16mx_epilogue_fusions():
+def test_conv_f16mx_epilogue_fusions(rows_tile):
     torch.manual_seed(2)
     B, C, M, L = 2, 24, 40, 50
     x, w, b = torch.randn(B, C, L), torch.randn(M, C, 3) / 8, torch.randn(M)
@@ -198,7 +205,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("cfg,shape,kw,permuted", CASES)
-def test_module_forward_backward_matches_oracle(cfg, shape, kw, permuted):
+def test_module_forward_backward_matches_oracle(cfg, shape, kw, permuted, rows_tile):
     torch.manual_seed(11)
     m = build(cfg, **kw)
     with torch.no_grad():
