@@ -51,7 +51,8 @@ __device__ __forceinline__ void fx_load_add16(const u16* p, long plane, long row
   }
 }
 
-__device__ __forceinline__ void fx_store16(u16* p, long plane, long row_elems, int c, float s_hi, float s_lo, const float (&v)[16]) {
+// returns bit e = (stored H[e] > 0)
+__device__ __forceinline__ unsigned fx_store16(u16* p, long plane, long row_elems, int c, float s_hi, float s_lo, const float (&v)[16]) {
   unsigned h[8], qh[4], ql[4];
   fx_split<16>(v, s_hi, s_lo, h, qh, ql);
   *(u32x4*)(p + row_elems + c) = u32x4{h[0], h[1], h[2], h[3]};
@@ -59,6 +60,13 @@ __device__ __forceinline__ void fx_store16(u16* p, long plane, long row_elems, i
   unsigned char* q = (unsigned char*)(p + plane) + row_elems * 2 + fx_q_off(c);
   *(u32x4*)q = u32x4{qh[0], qh[1], qh[2], qh[3]};
   *(u32x4*)(q + 32) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+  unsigned bt = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bt |= (((h[e] & 0x8000u) == 0 && (h[e] & 0x7fffu) != 0) ? 1u : 0u) << (2 * e);
+    bt |= (((h[e] & 0x80000000u) == 0 && (h[e] & 0x7fff0000u) != 0) ? 1u : 0u) << (2 * e + 1);
+  }
+  return bt;
 }
 
 // Register-direct epilogue of one wave's 128 (m) x 64 (rows) block held as 4 x 2 accumulators of 32x32.  Lane (j = lane &
@@ -98,6 +106,7 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
         for (int e = 0; e < 16; ++e) v[e] = 0.f;
         fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
         if (a.y2) fx_store16(a.y2, ax.y_plane, ro, cb, s_hi, s_lo, v);
+        if (a.bits_out) *(unsigned short*)(a.bits_out + ((ro + cb) >> 3)) = 0;
         continue;
       }
       if (a.bias) {
@@ -110,7 +119,11 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      if (a.mask) {   // the sign of a split value is the sign of its H plane (fp16 reaches 6e-8; smaller activations are zero)
+      if (a.mask_bits) {   // one bit per element, left behind by the ReLU'd launch that made the tensor: 1/16 of its H plane
+        const unsigned bt = *(const unsigned short*)(a.mask_bits + ((ro + cb) >> 3));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = ((bt >> e) & 1u) ? v[e] : 0.f;
+      } else if (a.mask) {   // the sign of a split value is the sign of its H plane (fp16 reaches 6e-8; smaller activations are zero)
         const u32x4 s0 = *(const u32x4*)(a.mask + ro + cb), s1 = *(const u32x4*)(a.mask + ro + cb + 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -120,7 +133,8 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
           v[8 + 2 * e + 1] = fx_h2f_hi(s1[e]) > 0.f ? v[8 + 2 * e + 1] : 0.f;
         }
       }
-      fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
+      const unsigned bt = fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
+      if (a.bits_out) *(unsigned short*)(a.bits_out + ((ro + cb) >> 3)) = (unsigned short)bt;
       if (a.y2) {
         fx_load_add16(a.post, ax.y_plane, ro, cb, s_lo, v);
         fx_store16(a.y2, ax.y_plane, ro, cb, s_hi, s_lo, v);
@@ -586,7 +600,7 @@ extern "C" int alvq_grad_scale_f32(const float* x, int64_t n, float* state, void
 
 extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
                                  const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M, int L,
-                                 int KW, int relu, const float* out_scale, void* stream) {
+                                 int KW, int relu, const void* mask_bits, void* relu_bits_out, const float* out_scale, void* stream) {
   ALVQ_REQUIRE(x && wp && (y || y_ncl), ALVQ_EINVAL, "alvq_conv1d_f16mx: null x/wp/y");
   ALVQ_REQUIRE(!(y && y_ncl), ALVQ_EINVAL, "alvq_conv1d_f16mx: choose one of y (NLC) and y_ncl (NCL fp32)");
   ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_f16mx: bad dims");
@@ -595,10 +609,13 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
   ALVQ_REQUIRE(!y_ncl || (!skip1 && !skip2 && !mask && !post && !relu), ALVQ_EUNSUPPORTED,
                "alvq_conv1d_f16mx: the NCL fp32 epilogue fuses bias (and the output scale) only");
   ALVQ_REQUIRE((long)B * (L + 1) < (1L << 30), ALVQ_EUNSUPPORTED, "alvq_conv1d_f16mx: problem too large");
+  ALVQ_REQUIRE(!(mask && mask_bits), ALVQ_EINVAL, "alvq_conv1d_f16mx: pass the mask as a tensor or as bits, not both");
+  ALVQ_REQUIRE(!y_ncl || (!mask_bits && !relu_bits_out), ALVQ_EUNSUPPORTED, "alvq_conv1d_f16mx: sign bits go with the NLC output");
   const long rows = alvq_nlc_rows(B, L);
   ConvFxArgs a{{(const u16*)x, (const u16*)wp, bias, (const u16*)skip1, (const u16*)skip2, (const u16*)mask, (const u16*)post,
                 (u16*)y, (u16*)y2, y_ncl, B, L, pad_to(C, 64), M, pad_to(M, 64), pad_to(M, WP_ROWS), relu ? 1 : 0,
-                (int)(rows / FX_R), pad_to(M, FX_M) / FX_M},   /* rtiles: see below */
+                (int)(rows / FX_R), pad_to(M, FX_M) / FX_M,   /* rtiles: see below */
+                (const unsigned char*)mask_bits, (unsigned char*)relu_bits_out},
                nlc_plane_elems(B, L, C), (long)alvq_packed_weight_elems(M, C, KW), nlc_plane_elems(B, L, M),
                FX_E_W, FX_E_ACT, out_scale, 0};
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)

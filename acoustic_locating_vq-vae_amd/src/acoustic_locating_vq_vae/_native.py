@@ -81,7 +81,7 @@ _SIGNATURES = {
     "alvq_ncl_to_nlc_f16mx": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p]),
     "alvq_nlc_to_ncl_f16mx": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p]),
     "alvq_relu_mask_f16mx": (_i32, [_c_void_p] * 3 + [_i32, _i32, _i32, _c_void_p]),
-    "alvq_conv1d_f16mx": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p, _c_void_p]),
+    "alvq_conv1d_f16mx": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p] * 4),
     "alvq_conv1d_wgrad_f16mx_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_f16mx": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p, _c_void_p]),
     "alvq_conv1d_wgrad_f16mx_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p, _c_void_p]),
@@ -503,9 +503,9 @@ class NLC:
     __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard", "planes", "has_bits", "fmt", "gscale")
 
     def __init__(self, B, L, C, device, planes=1, fmt=None, gscale=None):
-        """planes=2: the split-bf16 form (hi plane, then the lo plane at +alvq_nlc_plane_bytes).
-        planes=1 buffers carry a tail of rows*Cp/8 bytes for the sign bits a ReLU'd convolution can leave behind
-        (see alvq_conv1d_bf16); ``has_bits`` says whether they are valid."""
+        """planes=2: the split forms (hi / H plane, then the lo / Q plane at +alvq_nlc_plane_bytes).
+        bf16 and f16mx buffers carry a tail of rows*Cp/8 bytes for the sign bits a ReLU'd convolution can leave behind
+        (see alvq_conv1d_bf16 / alvq_conv1d_f16mx); ``has_bits`` says whether they are valid."""
         L_ = lib()
         self.B, self.L, self.C, self.planes = B, L, C, planes
         self.fmt = fmt or ("bf16x3" if planes == 2 else "bf16")
@@ -514,7 +514,7 @@ class NLC:
         self.rows = L_.alvq_nlc_rows(B, L)
         self.guard = L_.alvq_nlc_guard_rows()
         self.has_bits = False
-        n = planes * (self.rows + 2 * self.guard) * self.Cp + (self.rows * self.Cp // 16 if planes == 1 else 0)
+        n = planes * (self.rows + 2 * self.guard) * self.Cp + (self.rows * self.Cp // 16 if self.fmt != "bf16x3" else 0)
         self.storage = torch.empty((n,), device=device, dtype=torch.bfloat16)
 
     @classmethod
@@ -526,7 +526,8 @@ class NLC:
         self.gscale = None
         self.Cp, self.rows, self.guard = L_.alvq_nlc_channels(C), L_.alvq_nlc_rows(B, L), L_.alvq_nlc_guard_rows()
         self.storage = storage
-        self.has_bits = bool(has_bits) and storage.numel() >= (self.rows + 2 * self.guard) * self.Cp + self.rows * self.Cp // 16
+        self.has_bits = bool(has_bits) and self.fmt != "bf16x3" and \
+            storage.numel() >= planes * (self.rows + 2 * self.guard) * self.Cp + self.rows * self.Cp // 16
         return self
 
     @property
@@ -535,8 +536,8 @@ class NLC:
 
     @property
     def bits_ptr(self):
-        """Sign-bit area behind the matrix (planes == 1 only)."""
-        return self.storage.data_ptr() + (self.rows + 2 * self.guard) * self.Cp * 2
+        """Sign-bit area behind the plane(s) (bf16 and f16mx)."""
+        return self.storage.data_ptr() + self.planes * (self.rows + 2 * self.guard) * self.Cp * 2
 
     def matrix(self, plane=0):
         g = (self.guard + plane * (self.rows + 2 * self.guard)) * self.Cp
@@ -703,21 +704,22 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     # sign bits: a ReLU'd bf16 output records them; a mask operand that carries valid bits is passed as bits
     extra = ()
     mask_ptr = _nlc_ptr(mask, x, M, "mask")
-    if not split:
+    with_bits = x.fmt != "bf16x3"
+    if with_bits:
         mask_bits = None
         if mask is not None and mask.has_bits and USE_SIGN_BITS:
             mask_bits, mask_ptr = mask.bits_ptr, None
         bits_out = y.bits_ptr if (y is not None and relu and USE_SIGN_BITS) else None
         extra = (mask_bits, bits_out)
-    elif x.fmt == "f16mx":
-        extra = (_sptr(x.gscale, 1) if out_ncl else None,)      # a gradient leaving the format: divide the loss scale out
+    if x.fmt == "f16mx":
+        extra += (_sptr(x.gscale, 1) if out_ncl else None,)     # a gradient leaving the format: divide the loss scale out
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
         rc = fn(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),
                                     _nlc_ptr(skip2, x, M, "skip2"), mask_ptr,
                                     _nlc_ptr(post, x, M, "post"), y.ptr if y is not None else None,
                                     y2.ptr if y2 is not None else None, _ptr(y_ncl), x.B, C, M, x.L, KW,
                                     int(bool(relu)), *extra, _stream())
-    if not split and y is not None and relu and USE_SIGN_BITS:
+    if with_bits and y is not None and relu and USE_SIGN_BITS:
         y.has_bits = True
     _check(rc, "alvq_conv1d_bf16")
     if out_ncl:

@@ -282,7 +282,8 @@ int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* db
  *   alvq_grad_scale_f32    state[0] = S, state[1] = 1/S with S the power of two that puts amax|x| in [2^7, 2^8)
  *                          (state: 4 floats, zero-initialised by the caller once; re-armed by every call)
  *   alvq_ncl_to_nlc_f16mx  multiplies by *scale (NULL = 1) while converting; alvq_nlc_to_ncl_f16mx likewise on the way out
- *   alvq_conv1d_f16mx      y_ncl output multiplied by *out_scale (NULL = 1)
+ *   alvq_conv1d_f16mx      y_ncl output multiplied by *out_scale (NULL = 1); mask_bits / relu_bits_out as in
+ *                          alvq_conv1d_bf16 (one bit per element, [rows][Mp/8] bytes, bit = stored H > 0)
  *   alvq_conv1d_wgrad_f16mx  dw / dbias multiplied by *inv_scale (NULL = 1)
  * ============================================================================================== */
 int alvq_grad_scale_f32(const float* x, int64_t n, float* state, void* stream);
@@ -291,7 +292,8 @@ int alvq_nlc_to_ncl_f16mx(const void* x, float* y, int B, int C, int L, const fl
 int alvq_relu_mask_f16mx(const void* dy, const void* t, void* out, int B, int C, int L, void* stream);
 int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
                       const void* mask, const void* post, void* y, void* y2, float* y_ncl,
-                      int B, int C, int M, int L, int KW, int relu, const float* out_scale, void* stream);
+                      int B, int C, int M, int L, int KW, int relu, const void* mask_bits, void* relu_bits_out,
+                      const float* out_scale, void* stream);
 int64_t alvq_conv1d_wgrad_f16mx_workspace_bytes(int B, int C, int M, int L, int KW);
 int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
                             int B, int C, int M, int L, int KW, int w_layout, int accumulate,

@@ -93,6 +93,28 @@ def test_conv_f16mx_epilogue_fusions(rows_tile):
     assert int(qm[0].abs().sum()) == 0 and int(qm[1 + B * (L + 1):].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("M,KW", [(1024, 3), (1000, 1), (72, 3)])
+def test_relu_sign_bits_replace_the_mask_tensor_f16mx(M, KW, rows_tile):
+    """A ReLU'd f16mx output leaves the sign bits of its H plane behind (one byte per 8 channels of a row); the masked
+    launch that later needs "* (y > 0)" gives bit-identical results whether it reads those bits or the H plane."""
+    torch.manual_seed(31)
+    B, C, L = 3, 72, 140
+    x = torch.randn(B, C, L)
+    w = torch.randn(M, C, KW) / (C * KW) ** 0.5
+    t = N.conv1d_bf16(fx(x), N.pack_weight(w.cuda(), N.W_OIK, planes=3), relu=True)
+    assert t.has_bits
+    bits = t.storage.view(torch.uint8)[2 * (t.rows + 2 * t.guard) * t.Cp * 2:][:t.rows * t.Cp // 8].view(t.rows, t.Cp // 8)
+    want = (t.matrix(0).view(torch.float16).float() > 0).view(t.rows, t.Cp // 8, 8).to(torch.int32)
+    want = (want << torch.arange(8, device="cuda", dtype=torch.int32)).sum(dim=2).to(torch.uint8)
+    assert torch.equal(bits, want)
+    dy = fx(torch.randn(B, M, L))
+    pk = N.pack_weight(torch.randn(M, M, 1).cuda() / M ** 0.5, N.W_OIK, planes=3)
+    got_bits = N.conv1d_bf16(dy, pk, mask=t)                       # t.has_bits -> passed as bits
+    t_plain = N.NLC.wrap(t.storage, t.B, t.L, t.C, 2, has_bits=False, fmt="f16mx")
+    got_tensor = N.conv1d_bf16(dy, pk, mask=t_plain)
+    assert torch.equal(got_bits.matrix(0), got_tensor.matrix(0)) and torch.equal(got_bits.matrix(1), got_tensor.matrix(1))
+
+
 @pytest.mark.parametrize("B,C,M,L,KW", SHAPES)
 def test_wgrad_f16mx_matches_fp32(B, C, M, L, KW):
     torch.manual_seed(3)
