@@ -143,7 +143,7 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   }
 }
 
-// DBG: 1 run-time ablation switches, 2 also no fp16 MFMAs, 3 also no fp8 MFMAs, 4 the fp8 MFMAs issued as fp6.
+// DBG: 1 run-time ablation switches, 2 also no fp16 MFMAs, 3 also no fp8 MFMAs (timing experiments, tools/ablate_f16mx.sh).
 // NIN: 32-row blocks per wave.  2 = the 256-row tile; 1 = a 128-row tile (a wave owns 128 x 32) for launches whose 256-row
 // grid would leave CUs idle (one m-tile: M <= 256, or few rows) -- twice the workgroups at 5/4 instead of 6/8 fragment
 // reads per MFMA.
@@ -259,14 +259,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
       for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
 #define FX_H(MI, NI, KS) if (DBG != 2 && (NI) < NIN) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[MI][NI]) : "v"(aH[MI][KS]), "v"(bH[NI][KS]));
 #define FX_Q(MI, NI)                                                                          \
-  if ((NI) >= NIN) {                                                                            \
-  } else if (DBG == 4) {   /* timing probe: the same operands read as fp6 (e2m3), half the pipe cycles */ \
-    typedef int i32x6 __attribute__((ext_vector_type(6)));                                      \
-    const i32x6 a6_ = __builtin_shufflevector(aQ[MI], aQ[MI], 0, 1, 2, 3, 4, 5);                \
-    const i32x6 b6_ = __builtin_shufflevector(bQ[NI], bQ[NI], 0, 1, 2, 3, 4, 5);                \
-    asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" \
-        : "+v"(acc[MI][NI]) : "v"(a6_), "v"(b6_), "v"(sa), "v"(sb));                            \
-  } else if (DBG != 3)                                                                          \
+  if ((NI) < NIN && DBG != 3)                                                                          \
     asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"            \
         : "+v"(acc[MI][NI]) : "v"(aQ[MI]), "v"(bQ[NI]), "v"(sa), "v"(sb));
 #define FX_SB __builtin_amdgcn_sched_barrier(0);
@@ -635,7 +628,6 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
-    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
   }
   // fewer than ~3/4 of the CUs covered by 256-row tiles (one m-tile: M <= 256; short batches): 128-row tiles
   // (ALVQ_FX_ROWS=128|256 forces one of the two -- the tests run every shape through both)
@@ -647,7 +639,6 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
   if (dbg_env && y) {
     if (KW == 3 && (dbg_env & 16)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 2>), grid, block, FX_LDS, s, a);
     else if (KW == 3 && (dbg_env & 32)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 3>), grid, block, FX_LDS, s, a);
-    else if (KW == 3 && (dbg_env & 64)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 4>), grid, block, FX_LDS, s, a);
     else if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 1>), grid, block, FX_LDS, s, a);
     else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, 1>), grid, block, FX_LDS, s, a);
     return check_launch("alvq_conv1d_f16mx(dbg)");

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackBatch b) {
   const int KW = d.KW, tid = threadIdx.x;
   if (d.layout == ALVQ_W_OIK) {
     const int run = 64 * KW;
+#pragma unroll 4      // 8 KW iterations: four loads in flight instead of one round trip each
     for (int e = tid; e < 32 * run; e += 256) {
       const int mr = e / run, j = e - mr * run, c = j / KW, t = j - c * KW;
       const int m = m0 + mr;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackBatch b) {
     }
   } else {
     const int run = 32 * KW;
+#pragma unroll 4
     for (int e = tid; e < 64 * run; e += 256) {
       const int cc = e / run, j = e - cc * run, mr = j / KW, k = j - mr * KW;
       const int c = c0 + cc;
