@@ -58,6 +58,7 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
   if (full) {
     const float* p0 = partial + (long)(m0 + ty) * C + c;
     if (KW == 3) {
+#pragma unroll 2      // 24 loads in flight
       for (int k = 0; k < splits; ++k) {
         float2 v[3][4];
 #pragma unroll
@@ -73,6 +74,7 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
           }
       }
     } else {
+#pragma unroll 4
       for (int k = 0; k < splits; ++k) {
         float2 v[4];
 #pragma unroll
