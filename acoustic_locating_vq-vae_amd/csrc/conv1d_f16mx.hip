@@ -31,6 +31,7 @@ struct ConvFxArgs {
   long x_plane, wp_plane, y_plane;    // element (u16) offsets from an H plane to its Q plane
   int ea, eb;                         // E8M0 scale exponents: weights (A operand), activations / gradients (B operand and outputs)
   const float* out_scale;             // OUT == 1: device scalar multiplied into the fp32 output (undoes a loss scale), or null
+  unsigned long long* stamps;         // DBG instantiations, ALVQ_FX_DBG & 256: per workgroup {start, staged, main loop done, end} (100 MHz)
   int dbg;                            // ablation switches of the DBG instantiation (ALVQ_FX_DBG): 1 no in-loop DMA, 2 no in-loop
                                       // fragment reads, 4 no wait + barrier, 8 no epilogue -- timing experiments only
 };
@@ -74,6 +75,18 @@ __device__ __forceinline__ unsigned fx_store16(u16* p, long plane, long row_elem
 // of four.  Two rounds of v_permlane32_swap (groups 0 <-> 2, then 1 <-> 3) give the lane 16 CONSECUTIVE channels
 // (16 h .. 16 h + 15 of the tile), so every load and store is 16 bytes and the two lanes of a row cover one whole 64-byte
 // H segment and one whole 64-byte Q chunk.
+// Operand loads come FIRST and in bulk: one load -> use -> store chain per 32-channel tile made the epilogue a string of
+// eight L2 / HBM round trips (17 us per workgroup on an otherwise idle chip, before any bandwidth limit).  The skip and
+// mask operands of a whole 32-row block (four tiles, 48 + 32 registers -- the fragment registers are free by now) are
+// requested at once, and the second row block's while the first is being converted and stored.  Rows outside the data
+// (gap / tail rows: every plane holds them, as zeros) are loaded like any other and zeroed by a select, so the code has
+// no divergent branch.
+struct FxEpiLoads {
+  u32x4 h0[4], h1[4], ql[4];   // skip1: H (2 x 16 B) and lo8 of 16 channels, per 32-channel tile
+  u32x4 m0[4], m1[4];          // mask as a tensor: H
+  unsigned mb[4];              // mask as bits
+};
+
 template <int NIN>
 __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32x16 (&acc)[4][2], int m0, int r0, int lane, int wm0,
                                                  int wn0) {
@@ -81,65 +94,105 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   const int j = lane & 31, h = lane >> 5;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   const float s_lo = fx_pow2(ax.eb - FX_LO_SHIFT), s_hi = fx_pow2(ax.eb);
+  const int cb0 = m0 + wm0 + 16 * h;
+  FxEpiLoads ld[NIN];
+  auto request = [&](int ni) {
+    const long ro = (long)(r0 + wn0 + ni * 32 + j) * a.Mop;
 #pragma unroll
-  for (int ni = 0; ni < NIN; ++ni) {
+    for (int mi = 0; mi < 4; ++mi) {
+      if (m0 + wm0 + mi * 32 >= a.Mop) continue;        // Mop % 64 == 0: a 32-channel tile is inside or outside as a whole
+      const int cb = cb0 + mi * 32;
+      if (a.skip1) {
+        ld[ni].h0[mi] = *(const u32x4*)(a.skip1 + ro + cb);
+        ld[ni].h1[mi] = *(const u32x4*)(a.skip1 + ro + cb + 8);
+        ld[ni].ql[mi] = *(const u32x4*)((const unsigned char*)(a.skip1 + ax.y_plane) + ro * 2 + fx_q_off(cb) + 32);
+      }
+      if (a.mask_bits) {   // one bit per element, left behind by the ReLU'd launch that made the tensor: 1/16 of its H plane
+        ld[ni].mb[mi] = *(const unsigned short*)(a.mask_bits + ((ro + cb) >> 3));
+      } else if (a.mask) {
+        ld[ni].m0[mi] = *(const u32x4*)(a.mask + ro + cb);
+        ld[ni].m1[mi] = *(const u32x4*)(a.mask + ro + cb + 8);
+      }
+    }
+  };
+  auto tile = [&](int ni, int mi) {
+    if (m0 + wm0 + mi * 32 >= a.Mop) return;
     const int row = r0 + wn0 + ni * 32 + j;
     int b, l;
     const bool ok = row_valid(row, Lp1, ndata, &b, &l);
     const long ro = (long)row * a.Mop;
+    const int cb = cb0 + mi * 32;
+    float v[16];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      if (m0 + wm0 + mi * 32 >= a.Mop) continue;        // Mop % 64 == 0: a 32-channel tile is inside or outside as a whole
-      const int cb = m0 + wm0 + mi * 32 + 16 * h;
-      float v[16];
+    for (int e = 0; e < 4; ++e) {
+      const u32x2 ra = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][e]), __float_as_uint(acc[mi][ni][8 + e]), false, false);
+      const u32x2 rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][4 + e]), __float_as_uint(acc[mi][ni][12 + e]), false, false);
+      v[e] = __uint_as_float(ra[0]);
+      v[4 + e] = __uint_as_float(ra[1]);
+      v[8 + e] = __uint_as_float(rb[0]);
+      v[12 + e] = __uint_as_float(rb[1]);
+    }
+    if (a.bias) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += (cb + e < a.M) ? a.bias[cb + e] : 0.f;
+    }
+    if (a.skip1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const u32x2 ra = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][e]), __float_as_uint(acc[mi][ni][8 + e]), false, false);
-        const u32x2 rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[mi][ni][4 + e]), __float_as_uint(acc[mi][ni][12 + e]), false, false);
-        v[e] = __uint_as_float(ra[0]);
-        v[4 + e] = __uint_as_float(ra[1]);
-        v[8 + e] = __uint_as_float(rb[0]);
-        v[12 + e] = __uint_as_float(rb[1]);
-      }
-      if (!ok) {                                         // gap / tail rows stay zero in both planes
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = 0.f;
-        fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
-        if (a.y2) fx_store16(a.y2, ax.y_plane, ro, cb, s_hi, s_lo, v);
-        if (a.bits_out) *(unsigned short*)(a.bits_out + ((ro + cb) >> 3)) = 0;
-        continue;
-      }
-      if (a.bias) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += (cb + e < a.M) ? a.bias[cb + e] : 0.f;
-      }
-      if (a.skip1) fx_load_add16(a.skip1, ax.y_plane, ro, cb, s_lo, v);
-      if (a.skip2) fx_load_add16(a.skip2, ax.y_plane, ro, cb, s_lo, v);
-      if (a.relu & 1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (a.mask_bits) {   // one bit per element, left behind by the ReLU'd launch that made the tensor: 1/16 of its H plane
-        const unsigned bt = *(const unsigned short*)(a.mask_bits + ((ro + cb) >> 3));
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = ((bt >> e) & 1u) ? v[e] : 0.f;
-      } else if (a.mask) {   // the sign of a split value is the sign of its H plane (fp16 reaches 6e-8; smaller activations are zero)
-        const u32x4 s0 = *(const u32x4*)(a.mask + ro + cb), s1 = *(const u32x4*)(a.mask + ro + cb + 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] = fx_h2f_lo(s0[e]) > 0.f ? v[2 * e] : 0.f;
-          v[2 * e + 1] = fx_h2f_hi(s0[e]) > 0.f ? v[2 * e + 1] : 0.f;
-          v[8 + 2 * e] = fx_h2f_lo(s1[e]) > 0.f ? v[8 + 2 * e] : 0.f;
-          v[8 + 2 * e + 1] = fx_h2f_hi(s1[e]) > 0.f ? v[8 + 2 * e + 1] : 0.f;
-        }
-      }
-      const unsigned bt = fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
-      if (a.bits_out) *(unsigned short*)(a.bits_out + ((ro + cb) >> 3)) = (unsigned short)bt;
-      if (a.y2) {
-        fx_load_add16(a.post, ax.y_plane, ro, cb, s_lo, v);
-        fx_store16(a.y2, ax.y_plane, ro, cb, s_hi, s_lo, v);
+        float a0, a1, b0, b1;
+        fx_join2(ld[ni].h0[mi][e], ld[ni].ql[mi][e >> 1], (e & 1) * 2, s_lo, a0, a1);
+        fx_join2(ld[ni].h1[mi][e], ld[ni].ql[mi][2 + (e >> 1)], (e & 1) * 2, s_lo, b0, b1);
+        v[2 * e] += a0;
+        v[2 * e + 1] += a1;
+        v[8 + 2 * e] += b0;
+        v[8 + 2 * e + 1] += b1;
       }
     }
+    if (a.skip2) fx_load_add16(a.skip2, ax.y_plane, ro, cb, s_lo, v);
+    if (a.relu & 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (a.mask_bits) {
+      const unsigned bt = ld[ni].mb[mi];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = ((bt >> e) & 1u) ? v[e] : 0.f;
+    } else if (a.mask) {   // the sign of a split value is the sign of its H plane (fp16 reaches 6e-8; smaller activations are zero)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = fx_h2f_lo(ld[ni].m0[mi][e]) > 0.f ? v[2 * e] : 0.f;
+        v[2 * e + 1] = fx_h2f_hi(ld[ni].m0[mi][e]) > 0.f ? v[2 * e + 1] : 0.f;
+        v[8 + 2 * e] = fx_h2f_lo(ld[ni].m1[mi][e]) > 0.f ? v[8 + 2 * e] : 0.f;
+        v[8 + 2 * e + 1] = fx_h2f_hi(ld[ni].m1[mi][e]) > 0.f ? v[8 + 2 * e + 1] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;     // gap / tail rows stay zero in both planes
+    const unsigned bt = fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
+    if (a.bits_out) *(unsigned short*)(a.bits_out + ((ro + cb) >> 3)) = (unsigned short)bt;
+    if (a.y2) {
+      fx_load_add16(a.post, ax.y_plane, ro, cb, s_lo, v);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;
+      fx_store16(a.y2, ax.y_plane, ro, cb, s_hi, s_lo, v);
+    }
+  };
+  request(0);
+  __builtin_amdgcn_sched_barrier(0);
+  tile(0, 0);
+  tile(0, 1);
+  if (NIN > 1) {       // two tiles' accumulators and loads have been retired: room for the second row block's requests
+    __builtin_amdgcn_sched_barrier(0);
+    request(NIN - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  tile(0, 2);
+  tile(0, 3);
+  if (NIN > 1) {
+    tile(NIN - 1, 0);
+    tile(NIN - 1, 1);
+    tile(NIN - 1, 2);
+    tile(NIN - 1, 3);
   }
 }
 
@@ -268,6 +321,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   const int n = nch * KW;           // K-tiles
   const bool early = wave < 4;      // the two waves of a SIMD issue their DMA at different points of phase 2
 
+  unsigned long long st0 = 0, st1 = 0, st2 = 0;
+  if (DBG) st0 = __builtin_amdgcn_s_memrealtime();
   // ---- prologue: chunk 0's activation slabs, K-tiles 0 and 1 (and, for width 1, chunk 1's slabs) staged; H fragments of
   // K-tile 0 in registers
   issueX(0, 0);
@@ -280,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (DBG) st1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) { FX_RDH_A(0, mi, 0) FX_RDH_A(0, mi, 1) }
 #pragma unroll
@@ -354,12 +410,21 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   // the compiler's hazard recogniser does not see inside the asm MFMAs: cover the MFMA-result -> VALU-read wait states
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
+  if (DBG) st2 = __builtin_amdgcn_s_memrealtime();
   if (dbg & 8) {
     if (acc[0][0][0] == 12345.678f) a.y[0] = 1;   // keep the accumulators alive
     return;
   }
   if (OUT == 0) {
     wave_epilogue_fx<NIN>(ax, acc, m0, r0, lane, wm0, wn0);
+    if (DBG && (dbg & 256)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores have left
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long* o = ax.stamps + (long)blockIdx.x * 4;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
+      }
+    }
     return;
   }
   __syncthreads();   // the C slab overlays the stages: the trailing fragment reads of every wave must be done
@@ -610,7 +675,7 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
                 (int)(rows / FX_R), pad_to(M, FX_M) / FX_M,   /* rtiles: see below */
                 (const unsigned char*)mask_bits, (unsigned char*)relu_bits_out},
                nlc_plane_elems(B, L, C), (long)alvq_packed_weight_elems(M, C, KW), nlc_plane_elems(B, L, M),
-               FX_E_W, FX_E_ACT, out_scale, 0};
+               FX_E_W, FX_E_ACT, out_scale, nullptr, 0};
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
   a.dbg = dbg_env;
   hipStream_t s = (hipStream_t)stream;
@@ -637,10 +702,32 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
   if (half) a.b.rtiles = (int)(rows / 128);
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
   if (dbg_env && y) {
+    static unsigned long long* stamps = nullptr;
+    if ((dbg_env & 256) && !stamps) (void)hipMalloc(&stamps, 4096 * 4 * sizeof(unsigned long long));
+    a.stamps = stamps;
+    if (grid.x > 4096) a.dbg &= ~256;
     if (KW == 3 && (dbg_env & 16)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 2>), grid, block, FX_LDS, s, a);
     else if (KW == 3 && (dbg_env & 32)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 3>), grid, block, FX_LDS, s, a);
     else if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 1>), grid, block, FX_LDS, s, a);
     else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, 1>), grid, block, FX_LDS, s, a);
+    if (a.dbg & 256) {     // phase durations of this launch (means over its workgroups; first / last round by start time)
+      (void)hipStreamSynchronize(s);
+      static unsigned long long h[4096 * 4];
+      (void)hipMemcpy(h, stamps, grid.x * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (unsigned i = 0; i < grid.x; ++i) { if (h[4 * i] < t0) t0 = h[4 * i]; if (h[4 * i + 3] > t1) t1 = h[4 * i + 3]; }
+      double pro[2] = {0, 0}, mainl[2] = {0, 0}, epi[2] = {0, 0}, start[2] = {0, 0}; int cnt[2] = {0, 0};
+      for (unsigned i = 0; i < grid.x; ++i) {
+        const int rnd = (h[4 * i] - t0) * 4 > (t1 - t0) ? 1 : 0;     // started in the first quarter of the launch or later
+        pro[rnd] += h[4 * i + 1] - h[4 * i]; mainl[rnd] += h[4 * i + 2] - h[4 * i + 1]; epi[rnd] += h[4 * i + 3] - h[4 * i + 2];
+        start[rnd] += h[4 * i] - t0; ++cnt[rnd];
+      }
+      for (int r = 0; r < 2; ++r)
+        if (cnt[r])
+          fprintf(stderr, "[fx stamps] KW=%d M=%d C=%d round %d: %d workgroups, start +%.1f us, staging %.2f us, main loop %.2f us, epilogue %.2f us\n",
+                  KW, M, C, r, cnt[r], start[r] / cnt[r] / 100.0, pro[r] / cnt[r] / 100.0, mainl[r] / cnt[r] / 100.0, epi[r] / cnt[r] / 100.0);
+      fprintf(stderr, "[fx stamps] launch span %.1f us\n", (t1 - t0) / 100.0);
+    }
     return check_launch("alvq_conv1d_f16mx(dbg)");
   }
   if (half) {
