@@ -36,10 +36,9 @@ struct ConvFxArgs {
                                       // fragment reads, 4 no wait + barrier, 8 no epilogue -- timing experiments only
 };
 
-// 16 consecutive channels of one row, reconstructed from an f16mx tensor: += H + lo8 * S_lo
-__device__ __forceinline__ void fx_load_add16(const u16* p, long plane, long row_elems, int c, float s_lo, float (&v)[16]) {
-  const u32x4 h0 = *(const u32x4*)(p + row_elems + c), h1 = *(const u32x4*)(p + row_elems + c + 8);
-  const u32x4 ql = *(const u32x4*)((const unsigned char*)(p + plane) + row_elems * 2 + fx_q_off(c) + 32);
+// 16 consecutive channels of one row, reconstructed from an f16mx tensor: += H + lo8 * S_lo.  ph -> the row's H at the
+// first channel, pq -> the 64-byte Q chunk position of that channel (hi8; lo8 at +32).
+__device__ __forceinline__ void fx_join16(const u32x4& h0, const u32x4& h1, const u32x4& ql, float s_lo, float (&v)[16]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float a0, a1, b0, b1;
@@ -51,30 +50,30 @@ __device__ __forceinline__ void fx_load_add16(const u16* p, long plane, long row
     v[8 + 2 * e + 1] += b1;
   }
 }
+__device__ __forceinline__ void fx_load_add16(const u16* ph, const unsigned char* pq, float s_lo, float (&v)[16]) {
+  const u32x4 h0 = *(const u32x4*)ph, h1 = *(const u32x4*)(ph + 8);
+  const u32x4 ql = *(const u32x4*)(pq + 32);
+  fx_join16(h0, h1, ql, s_lo, v);
+}
 
-// returns bit e = (stored H[e] > 0)
-__device__ __forceinline__ unsigned fx_store16(u16* p, long plane, long row_elems, int c, float s_hi, float s_lo, const float (&v)[16]) {
+__device__ __forceinline__ void fx_store16(u16* ph, unsigned char* pq, float s_hi, float s_lo, const float (&v)[16]) {
   unsigned h[8], qh[4], ql[4];
   fx_split<16>(v, s_hi, s_lo, h, qh, ql);
-  *(u32x4*)(p + row_elems + c) = u32x4{h[0], h[1], h[2], h[3]};
-  *(u32x4*)(p + row_elems + c + 8) = u32x4{h[4], h[5], h[6], h[7]};
-  unsigned char* q = (unsigned char*)(p + plane) + row_elems * 2 + fx_q_off(c);
-  *(u32x4*)q = u32x4{qh[0], qh[1], qh[2], qh[3]};
-  *(u32x4*)(q + 32) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+  *(u32x4*)ph = u32x4{h[0], h[1], h[2], h[3]};
+  *(u32x4*)(ph + 8) = u32x4{h[4], h[5], h[6], h[7]};
+  *(u32x4*)pq = u32x4{qh[0], qh[1], qh[2], qh[3]};
+  *(u32x4*)(pq + 32) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+}
+
+// bit e = (the stored H of v[e] is > 0): fp16 rounds to a positive value exactly when v > 2^-25 (round to nearest even)
+__device__ __forceinline__ unsigned fx_sign_bits16(const float (&v)[16]) {
+  const float tiny = 2.98023223876953125e-8f;   // 2^-25
   unsigned bt = 0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bt |= (((h[e] & 0x8000u) == 0 && (h[e] & 0x7fffu) != 0) ? 1u : 0u) << (2 * e);
-    bt |= (((h[e] & 0x80000000u) == 0 && (h[e] & 0x7fff0000u) != 0) ? 1u : 0u) << (2 * e + 1);
-  }
+  for (int e = 15; e >= 0; --e) bt = (bt << 1) | (v[e] > tiny ? 1u : 0u);
   return bt;
 }
 
-// Register-direct epilogue of one wave's 128 (m) x 64 (rows) block held as 4 x 2 accumulators of 32x32.  Lane (j = lane &
-// 31, h = lane >> 5) holds, of row j of tile (mi, ni), the channels (q & 3) + 8 (q >> 2) + 4 h in register q: four groups
-// of four.  Two rounds of v_permlane32_swap (groups 0 <-> 2, then 1 <-> 3) give the lane 16 CONSECUTIVE channels
-// (16 h .. 16 h + 15 of the tile), so every load and store is 16 bytes and the two lanes of a row cover one whole 64-byte
-// H segment and one whole 64-byte Q chunk.
 // Operand loads come FIRST and in bulk: one load -> use -> store chain per 32-channel tile made the epilogue a string of
 // eight L2 / HBM round trips (17 us per workgroup on an otherwise idle chip, before any bandwidth limit).  The skip and
 // mask operands of a whole 32-row block (four tiles, 48 + 32 registers -- the fragment registers are free by now) are
@@ -94,24 +93,31 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   const int j = lane & 31, h = lane >> 5;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   const float s_lo = fx_pow2(ax.eb - FX_LO_SHIFT), s_hi = fx_pow2(ax.eb);
+  fx_saturating_conversions();
   const int cb0 = m0 + wm0 + 16 * h;
+  // Everything below addresses a row block through pointers to (row, channel cb0) computed once; a tile adds the
+  // constants 32 mi channels = 64 mi bytes of H, one Q chunk (64 bytes) per tile, 4 mi bytes of sign bits.
+  const long qo0 = fx_q_off(cb0);
   FxEpiLoads ld[NIN];
   auto request = [&](int ni) {
     const long ro = (long)(r0 + wn0 + ni * 32 + j) * a.Mop;
+    const u16* s1h = a.skip1 + ro + cb0;
+    const unsigned char* s1q = (const unsigned char*)(a.skip1 + ax.y_plane) + ro * 2 + qo0 + 32;
+    const u16* mkh = a.mask + ro + cb0;
+    const unsigned char* mkb = a.mask_bits + ((ro + cb0) >> 3);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       if (m0 + wm0 + mi * 32 >= a.Mop) continue;        // Mop % 64 == 0: a 32-channel tile is inside or outside as a whole
-      const int cb = cb0 + mi * 32;
       if (a.skip1) {
-        ld[ni].h0[mi] = *(const u32x4*)(a.skip1 + ro + cb);
-        ld[ni].h1[mi] = *(const u32x4*)(a.skip1 + ro + cb + 8);
-        ld[ni].ql[mi] = *(const u32x4*)((const unsigned char*)(a.skip1 + ax.y_plane) + ro * 2 + fx_q_off(cb) + 32);
+        ld[ni].h0[mi] = *(const u32x4*)(s1h + mi * 32);
+        ld[ni].h1[mi] = *(const u32x4*)(s1h + mi * 32 + 8);
+        ld[ni].ql[mi] = *(const u32x4*)(s1q + mi * 64);
       }
       if (a.mask_bits) {   // one bit per element, left behind by the ReLU'd launch that made the tensor: 1/16 of its H plane
-        ld[ni].mb[mi] = *(const unsigned short*)(a.mask_bits + ((ro + cb) >> 3));
+        ld[ni].mb[mi] = *(const unsigned short*)(mkb + mi * 4);
       } else if (a.mask) {
-        ld[ni].m0[mi] = *(const u32x4*)(a.mask + ro + cb);
-        ld[ni].m1[mi] = *(const u32x4*)(a.mask + ro + cb + 8);
+        ld[ni].m0[mi] = *(const u32x4*)(mkh + mi * 32);
+        ld[ni].m1[mi] = *(const u32x4*)(mkh + mi * 32 + 8);
       }
     }
   };
@@ -121,7 +127,8 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
     int b, l;
     const bool ok = row_valid(row, Lp1, ndata, &b, &l);
     const long ro = (long)row * a.Mop;
-    const int cb = cb0 + mi * 32;
+    const long hoff = ro + cb0 + mi * 32;                 // elements from a plane's start to this lane's 16 channels
+    const long qoff = ro * 2 + qo0 + mi * 64;             // bytes into the Q plane
     float v[16];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -133,22 +140,12 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
       v[12 + e] = __uint_as_float(rb[1]);
     }
     if (a.bias) {
+      const int cb = cb0 + mi * 32;
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] += (cb + e < a.M) ? a.bias[cb + e] : 0.f;
     }
-    if (a.skip1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a0, a1, b0, b1;
-        fx_join2(ld[ni].h0[mi][e], ld[ni].ql[mi][e >> 1], (e & 1) * 2, s_lo, a0, a1);
-        fx_join2(ld[ni].h1[mi][e], ld[ni].ql[mi][2 + (e >> 1)], (e & 1) * 2, s_lo, b0, b1);
-        v[2 * e] += a0;
-        v[2 * e + 1] += a1;
-        v[8 + 2 * e] += b0;
-        v[8 + 2 * e + 1] += b1;
-      }
-    }
-    if (a.skip2) fx_load_add16(a.skip2, ax.y_plane, ro, cb, s_lo, v);
+    if (a.skip1) fx_join16(ld[ni].h0[mi], ld[ni].h1[mi], ld[ni].ql[mi], s_lo, v);
+    if (a.skip2) fx_load_add16(a.skip2 + hoff, (const unsigned char*)(a.skip2 + ax.y_plane) + qoff, s_lo, v);
     if (a.relu & 1) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -166,15 +163,20 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
         v[8 + 2 * e + 1] = fx_h2f_hi(ld[ni].m1[mi][e]) > 0.f ? v[8 + 2 * e + 1] : 0.f;
       }
     }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;     // gap / tail rows stay zero in both planes
-    const unsigned bt = fx_store16(a.y, ax.y_plane, ro, cb, s_hi, s_lo, v);
-    if (a.bits_out) *(unsigned short*)(a.bits_out + ((ro + cb) >> 3)) = (unsigned short)bt;
-    if (a.y2) {
-      fx_load_add16(a.post, ax.y_plane, ro, cb, s_lo, v);
+    const bool gaps = !__all(ok);          // one 32-row block in sixteen holds a gap row: gap / tail rows stay zero
+    if (gaps) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;
-      fx_store16(a.y2, ax.y_plane, ro, cb, s_hi, s_lo, v);
+    }
+    fx_store16(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v);
+    if (a.bits_out) *(unsigned short*)(a.bits_out + (hoff >> 3)) = (unsigned short)fx_sign_bits16(v);
+    if (a.y2) {
+      fx_load_add16(a.post + hoff, (const unsigned char*)(a.post + ax.y_plane) + qoff, s_lo, v);
+      if (gaps) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;
+      }
+      fx_store16(a.y2 + hoff, (unsigned char*)(a.y2 + ax.y_plane) + qoff, s_hi, s_lo, v);
     }
   };
   request(0);
@@ -466,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
 __global__ __launch_bounds__(256) void ncl_to_nlc_fx_kernel(const float* x, u16* y, long plane, int B, int C, int L, int Cp,
                                                             int rows_total, int e, const float* scale) {
   __shared__ float tile[32][33];
+  fx_saturating_conversions();
   const int ct = Cp / 32;
   const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;

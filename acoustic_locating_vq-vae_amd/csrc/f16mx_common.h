@@ -45,24 +45,25 @@ constexpr int FX_LO_SHIFT = 11;    // lo8 is scaled by S * 2^-11
 
 __device__ __forceinline__ float fx_pow2(int e) { return __uint_as_float((unsigned)e << 23); }   // 2^(e-127), 1 <= e <= 254
 
-// two floats -> packed fp16 pair (RNE), saturating at +-65504 instead of overflowing to infinity (v_med3_f32 clamps)
+// Saturation comes from the wave's MODE register, not from clamps: with MODE.FP16_OVFL set, v_cvt_pk_f16_f32 returns
+// +-65504 and the fp8 conversions +-448 where they would return infinity / NaN (measured: tools/ovfl_probe.hip; the
+// clamps were 48 of the ~400 VALU instructions per 32 x 32 output tile of the convolution epilogue).  Every kernel that
+// converts INTO the format calls this once per wave before its first conversion (s_setreg is a scheduling barrier).
+__device__ __forceinline__ void fx_saturating_conversions() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }   // hwreg(MODE, 23, 1)
+
+// two floats -> packed fp16 pair (RNE); saturating at +-65504 under fx_saturating_conversions()
 __device__ __forceinline__ unsigned fx_f16_pk(float a, float b) {
-  const float m = 65504.f;
-  const f32x2 f = {__builtin_amdgcn_fmed3f(a, -m, m), __builtin_amdgcn_fmed3f(b, -m, m)};
+  const f32x2 f = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2_t));
 }
 __device__ __forceinline__ float fx_h2f_lo(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[0]; }
 __device__ __forceinline__ float fx_h2f_hi(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[1]; }
 
-// four floats -> four e4m3 bytes of v / s (RNE; s a power of two), saturating at +-448 s (the bare conversion returns NaN
-// above 464).  v_cvt_scalef32_pk_fp8_f32 divides by the scale inside the conversion.
+// four floats -> four e4m3 bytes of v / s (RNE; s a power of two), saturating at +-448 s under
+// fx_saturating_conversions() (the bare conversion returns NaN above 464).  v_cvt_scalef32_pk_fp8_f32 divides by the
+// scale inside the conversion.
 __device__ __forceinline__ unsigned fx_fp8x4(float a, float b, float c, float d, float s) {
   typedef short s16x2_t __attribute__((ext_vector_type(2)));
-  const float m = 448.f * s;
-  a = __builtin_amdgcn_fmed3f(a, -m, m);
-  b = __builtin_amdgcn_fmed3f(b, -m, m);
-  c = __builtin_amdgcn_fmed3f(c, -m, m);
-  d = __builtin_amdgcn_fmed3f(d, -m, m);
   s16x2_t r = {0, 0};
   r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a, b, s, false);
   r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, s, true);

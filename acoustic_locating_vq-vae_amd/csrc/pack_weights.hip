@@ -24,6 +24,7 @@ struct PackBatch {
 template <int PLANES>
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackBatch b) {
   __shared__ float tile[3][32][65];
+  if (PLANES == 3) fx_saturating_conversions();
   int di = 0;
   for (int i = 1; i < b.n; ++i)
     if ((int)blockIdx.x >= b.d[i].blk0) di = i;
