@@ -67,10 +67,11 @@ __device__ __forceinline__ void fx_store16(u16* ph, unsigned char* pq, float s_h
 
 // bit e = (the stored H of v[e] is > 0): fp16 rounds to a positive value exactly when v > 2^-25 (round to nearest even)
 __device__ __forceinline__ unsigned fx_sign_bits16(const float (&v)[16]) {
-  const float tiny = 2.98023223876953125e-8f;   // 2^-25
+  // as integers: bits(v) > bits(2^-25) = 0x33000000 (negative v are negative integers); the sign of the difference is
+  // the bit, shifted in from the right by v_alignbit_b32 -- two VALU instructions per element
   unsigned bt = 0;
 #pragma unroll
-  for (int e = 15; e >= 0; --e) bt = (bt << 1) | (v[e] > tiny ? 1u : 0u);
+  for (int e = 15; e >= 0; --e) bt = __builtin_amdgcn_alignbit(bt, 0x33000000u - __float_as_uint(v[e]), 31);
   return bt;
 }
 
@@ -150,10 +151,10 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    if (a.mask_bits) {
-      const unsigned bt = ld[ni].mb[mi];
+    if (a.mask_bits) {     // sign-extend bit e to a word and AND: two VALU instructions per element
+      const int bt = (int)ld[ni].mb[mi];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = ((bt >> e) & 1u) ? v[e] : 0.f;
+      for (int e = 0; e < 16; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (unsigned)((bt << (31 - e)) >> 31));
     } else if (a.mask) {   // the sign of a split value is the sign of its H plane (fp16 reaches 6e-8; smaller activations are zero)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {

@@ -88,8 +88,10 @@ __device__ __forceinline__ void fx_split(const float (&v)[N], float s, float s_l
 #pragma unroll
   for (int e = 0; e < N / 2; ++e) {
     h[e] = fx_f16_pk(v[2 * e], v[2 * e + 1]);
-    lo[2 * e] = v[2 * e] - fx_h2f_lo(h[e]);
-    lo[2 * e + 1] = v[2 * e + 1] - fx_h2f_hi(h[e]);
+    // v - H as ONE mixed-precision FMA reading the fp16 half directly (v_fma_mix_f32; the product by -1 is exact)
+    const f16x2_t hh = __builtin_bit_cast(f16x2_t, h[e]);
+    lo[2 * e] = __builtin_fmaf((float)hh[0], -1.0f, v[2 * e]);
+    lo[2 * e + 1] = __builtin_fmaf((float)hh[1], -1.0f, v[2 * e + 1]);
   }
 #pragma unroll
   for (int e = 0; e < N / 4; ++e) {
@@ -100,8 +102,11 @@ __device__ __forceinline__ void fx_split(const float (&v)[N], float s, float s_l
 
 // value of 2 consecutive channels from a packed fp16 pair and the matching lo8 bytes (word, first byte index b0)
 __device__ __forceinline__ void fx_join2(unsigned hpk, unsigned qlo, int b0, float s_lo, float& v0, float& v1) {
-  v0 = fx_h2f_lo(hpk) + fx_fp8_to_f(qlo, b0) * s_lo;
-  v1 = fx_h2f_hi(hpk) + fx_fp8_to_f(qlo, b0 + 1) * s_lo;
+  // lo8 * S_lo + H: the product by a power of two is exact, so the FMA (v_fma_mix_f32 on the fp16 half) rounds once
+  // like the sum did
+  const f16x2_t hh = __builtin_bit_cast(f16x2_t, hpk);
+  v0 = __builtin_fmaf(fx_fp8_to_f(qlo, b0), s_lo, (float)hh[0]);
+  v1 = __builtin_fmaf(fx_fp8_to_f(qlo, b0 + 1), s_lo, (float)hh[1]);
 }
 
 // byte offset of channel c (multiple of 8) inside a Q-plane row: 64 bytes per 32-channel chunk, hi8 first, lo8 at +32
