@@ -142,8 +142,17 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
     }
     if (a.bias) {
       const int cb = cb0 + mi * 32;
+      if (m0 + wm0 + mi * 32 + 32 <= a.M) {              // the whole 32-channel tile is real channels: four 16-byte loads
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] += (cb + e < a.M) ? a.bias[cb + e] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *(const f32x4*)(a.bias + cb + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] += bq[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += (cb + e < a.M) ? a.bias[cb + e] : 0.f;
+      }
     }
     if (a.skip1) fx_join16(ld[ni].h0[mi], ld[ni].h1[mi], ld[ni].ql[mi], s_lo, v);
     if (a.skip2) fx_load_add16(a.skip2 + hoff, (const unsigned char*)(a.skip2 + ax.y_plane) + qoff, s_lo, v);
