@@ -100,6 +100,15 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   // constants 32 mi channels = 64 mi bytes of H, one Q chunk (64 bytes) per tile, 4 mi bytes of sign bits.
   const long qo0 = fx_q_off(cb0);
   FxEpiLoads ld[NIN];
+  // per row block, once (the row -> (b, l) division is ~20 VALU instructions): is this lane's row a data row; does the
+  // block hold any row that is not
+  bool okr[NIN], gapsr[NIN];
+#pragma unroll
+  for (int ni = 0; ni < NIN; ++ni) {
+    int b, l;
+    okr[ni] = row_valid(r0 + wn0 + ni * 32 + j, Lp1, ndata, &b, &l);
+    gapsr[ni] = !__all(okr[ni]);
+  }
   auto request = [&](int ni) {
     const long ro = (long)(r0 + wn0 + ni * 32 + j) * a.Mop;
     const u16* s1h = a.skip1 + ro + cb0;
@@ -124,10 +133,8 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   };
   auto tile = [&](int ni, int mi) {
     if (m0 + wm0 + mi * 32 >= a.Mop) return;
-    const int row = r0 + wn0 + ni * 32 + j;
-    int b, l;
-    const bool ok = row_valid(row, Lp1, ndata, &b, &l);
-    const long ro = (long)row * a.Mop;
+    const bool ok = okr[ni], gaps = gapsr[ni];
+    const long ro = (long)(r0 + wn0 + ni * 32 + j) * a.Mop;
     const long hoff = ro + cb0 + mi * 32;                 // elements from a plane's start to this lane's 16 channels
     const long qoff = ro * 2 + qo0 + mi * 64;             // bytes into the Q plane
     float v[16];
@@ -173,8 +180,7 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
         v[8 + 2 * e + 1] = fx_h2f_hi(ld[ni].m1[mi][e]) > 0.f ? v[8 + 2 * e + 1] : 0.f;
       }
     }
-    const bool gaps = !__all(ok);          // one 32-row block in sixteen holds a gap row: gap / tail rows stay zero
-    if (gaps) {
+    if (gaps) {                            // one 32-row block in sixteen holds a gap row: gap / tail rows stay zero
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;
     }

@@ -77,6 +77,21 @@ def test_conv_f16mx_matches_fp32(B, C, M, L, KW, rows_tile):
     assert rel(N.conv1d_bf16(xn, N.pack_weight(wt.cuda(), N.W_IOK, planes=3), b.cuda(), out_ncl=True), reft) < KERNEL
 
 
+def test_conv_output_saturates_instead_of_overflowing(rows_tile):
+    """The conversions INTO the format saturate through the wave's MODE register (FP16_OVFL), with no clamp
+    instructions: a convolution output beyond fp16's range is stored as +-65504 (+ the largest lo8), never inf / NaN,
+    in the epilogue of both tiles as in the boundary conversion."""
+    B, C, M, L = 1, 32, 64, 40
+    x = torch.full((B, C, L), 300.0)
+    w = torch.full((M, C, 1), 50.0)
+    w[1::2] = -50.0
+    y = N.conv1d_bf16(fx(x), N.pack_weight(w.cuda(), N.W_OIK, planes=3)).to_ncl().cpu()     # +-480 000
+    assert torch.isfinite(y).all()
+    assert float((y[:, 0::2] - 65504.0).abs().max()) < 1 and float((y[:, 1::2] + 65504.0).abs().max()) < 1
+    h = N.conv1d_bf16(fx(x), N.pack_weight(w.cuda(), N.W_OIK, planes=3)).matrix(0).view(torch.float16)
+    assert torch.isfinite(h.float()).all()
+
+
 def test_conv_f16mx_epilogue_fusions(rows_tile):
     torch.manual_seed(2)
     B, C, M, L = 2, 24, 40, 50
