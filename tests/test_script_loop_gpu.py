@@ -89,7 +89,7 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16x3", 2e-3)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16x3", 2e-3), ("f16mx", 2e-3)])
 def test_speech_script_loop_tracks_the_cpu_reference_path(dtype, tol):
     from acoustic_locating_vq_vae import _ops
     cfg = (20, 48, 8, 2, 24, 0.25, 64)          # in, H, D, R, RH, beta, K
