@@ -32,8 +32,9 @@ struct ConvFxArgs {
   int ea, eb;                         // E8M0 scale exponents: weights (A operand), activations / gradients (B operand and outputs)
   const float* out_scale;             // OUT == 1: device scalar multiplied into the fp32 output (undoes a loss scale), or null
   unsigned long long* stamps;         // DBG instantiations, ALVQ_FX_DBG & 256: per workgroup {start, staged, main loop done, end} (100 MHz)
-  int dbg;                            // ablation switches of the DBG instantiation (ALVQ_FX_DBG): 1 no in-loop DMA, 2 no in-loop
-                                      // fragment reads, 4 no wait + barrier, 8 no epilogue -- timing experiments only
+  int dbg;                            // switches of the DBG instantiations (ALVQ_FX_DBG), timing experiments only: 1 no in-loop
+                                      // DMA, 2 no in-loop fragment reads, 4 no wait + barrier, 8 no epilogue, 16 / 32 no fp16 /
+                                      // no fp8 MFMAs, 256 phase stamps (results intact), 512 stamps + the epilogue's stores removed
 };
 
 // 16 consecutive channels of one row, reconstructed from an f16mx tensor: += H + lo8 * S_lo.  ph -> the row's H at the
@@ -56,9 +57,15 @@ __device__ __forceinline__ void fx_load_add16(const u16* ph, const unsigned char
   fx_join16(h0, h1, ql, s_lo, v);
 }
 
+template <bool NOSTORE = false>
 __device__ __forceinline__ void fx_store16(u16* ph, unsigned char* pq, float s_hi, float s_lo, const float (&v)[16]) {
   unsigned h[8], qh[4], ql[4];
   fx_split<16>(v, s_hi, s_lo, h, qh, ql);
+  if (NOSTORE) {   // timing ablation (ALVQ_FX_DBG & 512): the conversions stay, the stores go
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(h[e]), "v"(h[4 + e]), "v"(qh[e]), "v"(ql[e]));
+    return;
+  }
   *(u32x4*)ph = u32x4{h[0], h[1], h[2], h[3]};
   *(u32x4*)(ph + 8) = u32x4{h[4], h[5], h[6], h[7]};
   *(u32x4*)pq = u32x4{qh[0], qh[1], qh[2], qh[3]};
@@ -87,7 +94,7 @@ struct FxEpiLoads {
   unsigned mb[4];              // mask as bits
 };
 
-template <int NIN>
+template <int NIN, int DBG = 0>
 __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32x16 (&acc)[4][2], int m0, int r0, int lane, int wm0,
                                                  int wn0) {
   const ConvBArgs& a = ax.b;
@@ -184,7 +191,8 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;
     }
-    fx_store16(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v);
+    if (DBG && (ax.dbg & 512)) fx_store16<true>(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v);
+    else fx_store16(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v);
     if (a.bits_out) *(unsigned short*)(a.bits_out + (hoff >> 3)) = (unsigned short)fx_sign_bits16(v);
     if (a.y2) {
       fx_load_add16(a.post + hoff, (const unsigned char*)(a.post + ax.y_plane) + qoff, s_lo, v);
@@ -434,8 +442,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
     return;
   }
   if (OUT == 0) {
-    wave_epilogue_fx<NIN>(ax, acc, m0, r0, lane, wm0, wn0);
-    if (DBG && (dbg & 256)) {
+    wave_epilogue_fx<NIN, DBG>(ax, acc, m0, r0, lane, wm0, wn0);
+    if (DBG && (dbg & (256 | 512))) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores have left
       __syncthreads();
       if (tid == 0) {
@@ -722,14 +730,14 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
   if (dbg_env && y) {
     static unsigned long long* stamps = nullptr;
-    if ((dbg_env & 256) && !stamps) (void)hipMalloc(&stamps, 4096 * 4 * sizeof(unsigned long long));
+    if ((dbg_env & (256 | 512)) && !stamps) (void)hipMalloc(&stamps, 4096 * 4 * sizeof(unsigned long long));
     a.stamps = stamps;
-    if (grid.x > 4096) a.dbg &= ~256;
+    if (grid.x > 4096) a.dbg &= ~(256 | 512);
     if (KW == 3 && (dbg_env & 16)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 2>), grid, block, FX_LDS, s, a);
     else if (KW == 3 && (dbg_env & 32)) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 3>), grid, block, FX_LDS, s, a);
     else if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 1>), grid, block, FX_LDS, s, a);
     else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, 1>), grid, block, FX_LDS, s, a);
-    if (a.dbg & 256) {     // phase durations of this launch (means over its workgroups; first / last round by start time)
+    if (a.dbg & (256 | 512)) {     // phase durations of this launch (means over its workgroups; first / last round by start time)
       (void)hipStreamSynchronize(s);
       static unsigned long long h[4096 * 4];
       (void)hipMemcpy(h, stamps, grid.x * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
