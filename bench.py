@@ -375,6 +375,10 @@ def main():
                                      % (cfgname, 2 if cfgname == "rir" else 4, args.dtype),
                          "value": r["value"], "unit": "spectrograms/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                          "launch": r["launch"], "model_tflops": r["model_tflops"], "algorithmic_gflop_per_spectrogram": gf2}
+            if args.dtype != PARITY_MODES[0]:      # the same config in the mode that carries the parity claim
+                r2, _, _ = run_config(cfgname, PARITY_MODES[0], 32, max(5, min(20, args.steps)), 3, graph=not args.no_graph, timer=False)
+                line[key]["parity_mode"] = {"dtype": PARITY_MODES[0], "value": r2["value"], "ms_per_step": r2["ms_per_step"],
+                                            "model_tflops": r2["model_tflops"]}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
