@@ -72,6 +72,45 @@ def test_fuzz_bf16(B, C, M, L, KW, planes, tol):
         assert float(mat[:, :, M:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("rows_tile", ["128", "256"])
+@pytest.mark.parametrize("B,C,M,L,KW", CASES)
+def test_fuzz_f16mx(B, C, M, L, KW, rows_tile, monkeypatch):
+    """The same 40 shapes through the f16mx kernels (fp16 + block-scaled fp8 MFMA per product), both row tiles of the
+    convolution: ~1.5e-5 per product against the fp32 result; gap / tail rows and padded channels of both planes zero;
+    the sign bits a ReLU'd output leaves behind are the signs of its H plane."""
+    monkeypatch.setenv("ALVQ_FX_ROWS", rows_tile)
+    tol = 1.5e-4
+    g = torch.Generator().manual_seed(B * 7919 + C * 31 + M * 17 + L * 3 + KW + 5)
+    x = torch.randn(B, C, L, generator=g).requires_grad_(True)
+    w = (torch.randn(M, C, KW, generator=g) / (C * KW) ** 0.5).requires_grad_(True)
+    b = torch.randn(M, generator=g, requires_grad=True)
+    dy = torch.randn(B, M, L, generator=g)
+    y = F.conv1d(x, w, b, padding=KW // 2)
+    y.backward(dy)
+    xn, dyn = N.ncl_to_nlc(x.detach().cuda(), 2, "f16mx"), N.ncl_to_nlc(dy.cuda(), 2, "f16mx")
+    wd = w.detach().cuda()
+    assert rel(N.conv1d_bf16(xn, N.pack_weight(wd, N.W_OIK, 3), b.detach().cuda(), out_ncl=True), y) < tol
+    assert rel(N.conv1d_bf16(dyn, N.pack_weight(wd, N.W_IOK, 3), out_ncl=True), x.grad) < tol
+    dw, db = N.conv1d_wgrad_bf16(dyn, xn, KW, want_bias=True)
+    assert rel(dw, w.grad) < 2 * tol
+    assert float((db.cpu() - b.grad).abs().max()) <= 1e-4 * float(dy.abs().sum(dim=(0, 2)).max()) + 1e-30
+    out = N.conv1d_bf16(xn, N.pack_weight(wd, N.W_OIK, 3), b.detach().cuda(), relu=True)
+    assert rel(out.to_ncl(), F.relu(y)) < tol
+    hm = out.matrix(0).view(torch.float16).float()
+    qm = out.matrix(1).view(torch.int16)
+    gaps = torch.arange(0, B * (L + 1) + 1, L + 1, device="cuda")
+    assert float(hm[gaps].abs().max()) == 0.0 and int(qm[gaps].abs().max()) == 0
+    if B * (L + 1) + 1 < out.rows:
+        assert float(hm[B * (L + 1) + 1:].abs().max()) == 0.0 and int(qm[B * (L + 1) + 1:].abs().max()) == 0
+    if M < out.Cp:
+        assert float(hm[:, M:].abs().max()) == 0.0
+    assert out.has_bits
+    bits = out.storage.view(torch.uint8)[2 * (out.rows + 2 * out.guard) * out.Cp * 2:][:out.rows * out.Cp // 8].view(out.rows, out.Cp // 8)
+    want = (hm > 0).view(out.rows, out.Cp // 8, 8).to(torch.int32)
+    want = (want << torch.arange(8, device="cuda", dtype=torch.int32)).sum(dim=2).to(torch.uint8)
+    assert torch.equal(bits, want)
+
+
 VQ_CASES = [(int(r.choice([1, 63, 64, 65, 777, 4097])), int(r.choice([1, 2, 16, 100, 513, 1024])),
              int(r.choice([1, 4, 31, 64, 100, 128, 200, 256, 300, 512])))
             for r in (np.random.default_rng(2000 + i) for i in range(30))]
