@@ -226,19 +226,22 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
 // NIN: 32-row blocks per wave.  2 = the 256-row tile; 1 = a 128-row tile (a wave owns 128 x 32) for launches whose 256-row
 // grid would leave CUs idle (one m-tile: M <= 256, or few rows) -- twice the workgroups at 5/4 instead of 6/8 fragment
 // reads per MFMA.
-template <int OUT, int KW, int DBG = 0, int NIN = 2>
+// MIN: 32-channel blocks per wave.  4 = the 256-channel m-tile; 2 = a 128-channel m-tile (a wave owns 64 x 32, with
+// NIN = 1) for layers of at most 128 output channels, whose 256-wide tile would spend half of its MFMAs on padding.
+template <int OUT, int KW, int DBG = 0, int NIN = 2, int MIN = 4>
 __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   constexpr int PAD = (KW - 1) / 2;
   constexpr int RT = 128 * NIN;          // rows per workgroup
+  constexpr int MT = 64 * MIN;           // output channels per workgroup
   const int dbg = DBG ? ax.dbg : 0;
   const ConvBArgs& a = ax.b;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 32 * NIN;
+  const int wm0 = (wave >> 2) * 32 * MIN, wn0 = (wave & 3) * 32 * NIN;
 
   const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int m0 = (tile % a.mtiles) * FX_M;
+  const int m0 = (tile % a.mtiles) * MT;
   const int r0 = (tile / a.mtiles) * RT;
   const int Cp = a.Cp;
 
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   // K-tile t -> weight stage t & 1: 32 rows of W.H and of W.Q per wave = pieces 0..3 (issued one at a time so that each
   // can sit in the shadow of an MFMA)
   auto pieceW = [&](int t, int k) {
+    if (wave * 32 >= MT) return;          // 128-channel m-tile: waves 0-3 stage the weight rows
     const int chunk = t / KW, tap = t - chunk * KW;
     const unsigned dst = lds0 + (t & 1) * FX_WSTAGE + wave * 2048 + (k >> 1) * FX_SLAB + (k & 1) * 1024;
     dma(wb + tap * tap_w + chunk * (FX_K * 2) + (k >> 1) * wpl + (k & 1) * row16, dst);
@@ -313,14 +317,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   f16x8_t aH[4][2], bH[2][2];
   i32x8 aQ[4], bQ[2];
-#define FX_RDH_A(WS, MI, KS) aH[MI][KS] = *(const f16x8_t*)(abase + (WS) * FX_WSTAGE + (MI) * 2048 + offA[KS]);
+#define FX_RDH_A(WS, MI, KS) if ((MI) < MIN) aH[MI][KS] = *(const f16x8_t*)(abase + (WS) * FX_WSTAGE + (MI) * 2048 + offA[KS]);
 #define FX_RDH_B(XS, TAP, NI, KS) if ((NI) < NIN) bH[NI][KS] = *(const f16x8_t*)(bbase + (XS) * FX_XSTAGE + (NI) * 2048 + offB[TAP][KS]);
 #define FX_RDQ(DST, P, FIRST, SECOND)                                                           \
   {                                                                                             \
     const i32x4 q0_ = *(const i32x4*)((P) + (FIRST)), q1_ = *(const i32x4*)((P) + (SECOND));    \
     DST = __builtin_shufflevector(q0_, q1_, 0, 1, 2, 3, 4, 5, 6, 7);                            \
   }
-#define FX_RDQ_A(WS, MI) FX_RDQ(aQ[MI], abase + (WS) * FX_WSTAGE + FX_SLAB + (MI) * 2048, offA[0], offA[1])
+#define FX_RDQ_A(WS, MI) if ((MI) < MIN) FX_RDQ(aQ[MI], abase + (WS) * FX_WSTAGE + FX_SLAB + (MI) * 2048, offA[0], offA[1])
 #define FX_RDQ_B(XS, TAP, NI) if ((NI) < NIN) FX_RDQ(bQ[NI], bbase + (XS) * FX_XSTAGE + FX_XSLAB + (NI) * 2048, offB[TAP][1], offB[TAP][0])
 
   // block scales of the fp8 MFMA: lanes 0-31 supply block 0, lanes 32-63 block 1.  Opaque to the compiler so that it keeps
@@ -336,9 +340,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][jn][q] = 0.f;
-#define FX_H(MI, NI, KS) if (DBG != 2 && (NI) < NIN) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[MI][NI]) : "v"(aH[MI][KS]), "v"(bH[NI][KS]));
+#define FX_H(MI, NI, KS) if (DBG != 2 && (NI) < NIN && (MI) < MIN) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[MI][NI]) : "v"(aH[MI][KS]), "v"(bH[NI][KS]));
 #define FX_Q(MI, NI)                                                                          \
-  if ((NI) < NIN && DBG != 3)                                                                          \
+  if ((NI) < NIN && (MI) < MIN && DBG != 3)                                                                        \
     asm("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"            \
         : "+v"(acc[MI][NI]) : "v"(aQ[MI]), "v"(bQ[NI]), "v"(sa), "v"(sb));
 #define FX_SB __builtin_amdgcn_sched_barrier(0);
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   __builtin_amdgcn_s_barrier();
   if (DBG) st1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) { FX_RDH_A(0, mi, 0) FX_RDH_A(0, mi, 1) }
+  for (int mi = 0; mi < MIN; ++mi) { FX_RDH_A(0, mi, 0) FX_RDH_A(0, mi, 1) }
 #pragma unroll
   for (int ni = 0; ni < NIN; ++ni) { FX_RDH_B(0, 0, ni, 0) FX_RDH_B(0, 0, ni, 1) }
 
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   for (int slab = 0; slab < RT / 64; ++slab) {
     if ((wn0 >> 6) == slab) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MIN; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NIN; ++ni)
 #pragma unroll
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
       const int rl = tid & 63, row = r0 + slab * 64 + rl;
       int b, l;
       if (row_valid(row, Lp1, ndata, &b, &l)) {
-        for (int ml = tid >> 6; ml < FX_M; ml += 8) {
+        for (int ml = tid >> 6; ml < MT; ml += 8) {
           const int m = m0 + ml;
           if (m >= a.M) break;
           a.y_ncl[((long)b * a.M + m) * a.L + l] = (Cs[rl * FX_CS + ml] + (a.bias ? a.bias[m] : 0.f)) * oscale;
@@ -716,6 +720,8 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 3, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 1, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
@@ -725,7 +731,10 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
   // (ALVQ_FX_ROWS=128|256 forces one of the two -- the tests run every shape through both)
   const char* force = getenv("ALVQ_FX_ROWS");
   const int forced = force ? atoi(force) : 0;
-  const bool half = !dbg_env && (forced == 128 || (forced != 256 && a.b.rtiles * a.b.mtiles < 192));
+  // fp32-NCL output of at most 128 channels (the pre-VQ convolution and the data gradient that leaves the decoder): a
+  // 128-channel m-tile on 128-row tiles -- no MFMA spent on padding channels (ALVQ_FX_NARROW=0 switches it off)
+  const bool narrow = !dbg_env && y_ncl && M <= 128 && !(getenv("ALVQ_FX_NARROW") && atoi(getenv("ALVQ_FX_NARROW")) == 0);
+  const bool half = narrow || (!dbg_env && (forced == 128 || (forced != 256 && a.b.rtiles * a.b.mtiles < 192)));
   if (half) a.b.rtiles = (int)(rows / 128);
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
   if (dbg_env && y) {
@@ -757,7 +766,10 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
     }
     return check_launch("alvq_conv1d_f16mx(dbg)");
   }
-  if (half) {
+  if (narrow) {
+    if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<1, 3, 0, 1, 2>), grid, block, FX_LDS, s, a);
+    else hipLaunchKernelGGL((conv1d_f16mx_kernel<1, 1, 0, 1, 2>), grid, block, FX_LDS, s, a);
+  } else if (half) {
     if (y) {
       if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 3, 0, 1>), grid, block, FX_LDS, s, a);
       else hipLaunchKernelGGL((conv1d_f16mx_kernel<0, 1, 0, 1>), grid, block, FX_LDS, s, a);
