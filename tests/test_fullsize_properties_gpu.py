@@ -93,6 +93,43 @@ def test_bf16_conv_adjoint_wgrad_fullsize(C, M, KW, planes, tol):
     close(dot(dW, V), dot(yv, dy), tol)
 
 
+@pytest.mark.parametrize("C,M,KW", SHAPES)
+def test_f16mx_conv_adjoint_wgrad_fullsize(C, M, KW):
+    """The same size-independent identities through the f16mx kernels at BASELINE's full sizes (B=64 x 500 rows): the
+    forward and the data-gradient launch are adjoint, the weight gradient is the forward's derivative in W; ~1.5e-5 per
+    product, and the inner products of independent random operands are ~sqrt(N) smaller than the norms."""
+    x, dy = rnd(B, C, L, seed=31), rnd(B, M, L, seed=32)
+    W = rnd(M, C, KW, seed=33, scale=(C * KW) ** -0.5)
+    V = rnd(M, C, KW, seed=34, scale=(C * KW) ** -0.5)
+    xn, dyn = N.ncl_to_nlc(x, 2, "f16mx"), N.ncl_to_nlc(dy, 2, "f16mx")
+    y = N.conv1d_bf16(xn, N.pack_weight(W, N.W_OIK, 3), out_ncl=True)
+    dx = N.conv1d_bf16(dyn, N.pack_weight(W, N.W_IOK, 3), out_ncl=True)
+    assert tuple(y.shape) == (B, M, L) and tuple(dx.shape) == (B, C, L)
+    close(dot(y, dy), dot(x, dx), 1e-3)
+    dW = N.conv1d_wgrad_bf16(dyn, xn, KW)
+    yv = N.conv1d_bf16(xn, N.pack_weight(V, N.W_OIK, 3), out_ncl=True)
+    close(dot(dW, V), dot(yv, dy), 1e-3)
+    # against the exact-fp32 kernels on the same operands
+    ref = N.conv1d(x, W)
+    assert float((y - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("KW", [1, 3])
+def test_f16mx_conv_sample_independence_and_gap_rows_fullsize(KW):
+    C = M = 1024
+    x = rnd(B, C, L, seed=35)
+    pk = N.pack_weight(rnd(M, C, KW, seed=36, scale=(C * KW) ** -0.5), N.W_OIK, 3)
+    b = rnd(M, seed=37)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(38)).cuda()
+    y = N.conv1d_bf16(N.ncl_to_nlc(x, 2, "f16mx"), pk, b, relu=True)
+    yp = N.conv1d_bf16(N.ncl_to_nlc(x[perm].contiguous(), 2, "f16mx"), pk, b, relu=True)
+    assert torch.equal(N.nlc_to_ncl(yp), N.nlc_to_ncl(y)[perm])
+    gaps = torch.arange(0, B * (L + 1) + 1, L + 1, device="cuda")
+    for plane in (0, 1):
+        mat = y.matrix(plane).view(torch.int16)
+        assert int(mat[gaps].abs().max()) == 0 and int(mat[B * (L + 1) + 1:].abs().max()) == 0
+
+
 @pytest.mark.parametrize("KW", [1, 3])
 def test_bf16_conv_sample_independence_and_gap_rows_fullsize(KW):
     C = M = 1024
@@ -189,7 +226,7 @@ def test_jitter_standardise_adam_fullsize():
 
 
 # ------------------------------------------------------------------------------------------------- the whole step
-@pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3", "f16mx"])
 def test_train_step_invariants_fullsize(dtype):
     from acoustic_locating_vq_vae import _ops
     from acoustic_locating_vq_vae.train_step import Trainer
