@@ -36,39 +36,43 @@ static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int 
 }
 
 // IOK output (ConvTranspose1d weights): the loop above would read the partials with a stride of C floats between
-// neighbouring lanes.  Here a workgroup owns a 32 (m) x 64 (c) tile for all taps: partials are read with lanes along c
+// neighbouring lanes.  Here a workgroup owns an RB (m) x 64 (c) tile for all taps: partials are read with lanes along c
 // (their contiguous axis), summed in split order, and the tile is turned through LDS so that the writes are
 // (m, tap) runs of one c -- the contiguous axis of dw[c][m][KW-1-t].
+// RB rows (m) x 64 columns (c) per workgroup; RB = 16 gives a 1024 x 1024 weight 1024 workgroups of 256 threads with
+// RB / 8 x KW 8-byte loads in flight each -- at RB = 32 (512 workgroups) the kernel ran at 2 TB/s.
+template <int RB>
 static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const float* partial, float* dw, int splits, int KW,
                                                                       int M, int C, int accumulate) {
-  __shared__ float tile[3][32][65];
+  constexpr int RI = RB / 8;           // rows per thread
+  __shared__ float tile[3][RB][65];
   const int ctiles = (C + 63) / 64;
-  const int m0 = (blockIdx.x / ctiles) * 32, c0 = (blockIdx.x % ctiles) * 64;
+  const int m0 = (blockIdx.x / ctiles) * RB, c0 = (blockIdx.x % ctiles) * 64;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const long plane = (long)M * C, total = (long)KW * plane;
   const bool pair = (C % 2 == 0);          // 8-byte loads need an even row stride
-  // all 12 (tap, row) sums of a thread advance together, one split at a time: 12 independent loads in flight
-  float s0[3][4], s1[3][4];
+  // all (tap, row) sums of a thread advance together, one split at a time: RI x KW independent loads in flight
+  float s0[3][RI], s1[3][RI];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s0[t][i] = s1[t][i] = 0.f;
+    for (int i = 0; i < RI; ++i) s0[t][i] = s1[t][i] = 0.f;
   const int c = c0 + 2 * tx;
-  const bool full = pair && m0 + 32 <= M && c0 + 64 <= C;     // interior tile: no per-element bounds, loads batch up
+  const bool full = pair && m0 + RB <= M && c0 + 64 <= C;     // interior tile: no per-element bounds, loads batch up
   if (full) {
     const float* p0 = partial + (long)(m0 + ty) * C + c;
     if (KW == 3) {
-#pragma unroll 2      // 24 loads in flight
+#pragma unroll 4
       for (int k = 0; k < splits; ++k) {
-        float2 v[3][4];
+        float2 v[3][RI];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[t][i] = *(const float2*)(p0 + (long)k * total + (long)t * plane + (long)(8 * i) * C);
+          for (int i = 0; i < RI; ++i) v[t][i] = *(const float2*)(p0 + (long)k * total + (long)t * plane + (long)(8 * i) * C);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < RI; ++i) {
             s0[t][i] += v[t][i].x;
             s1[t][i] += v[t][i].y;
           }
@@ -76,11 +80,11 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
     } else {
 #pragma unroll 4
       for (int k = 0; k < splits; ++k) {
-        float2 v[4];
+        float2 v[RI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *(const float2*)(p0 + (long)k * total + (long)(8 * i) * C);
+        for (int i = 0; i < RI; ++i) v[i] = *(const float2*)(p0 + (long)k * total + (long)(8 * i) * C);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RI; ++i) {
           s0[0][i] += v[i].x;
           s1[0][i] += v[i].y;
         }
@@ -93,7 +97,7 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
     for (int t = 0; t < 3; ++t) {
       if (t >= KW) break;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RI; ++i) {
         const int m = m0 + ty + 8 * i;
         if (m >= M) continue;
         const float* p = pk + (long)t * plane + (long)m * C;
@@ -112,13 +116,13 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
   for (int t = 0; t < 3; ++t) {
     if (t >= KW) break;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RI; ++i) {
       tile[t][ty + 8 * i][2 * tx] = s0[t][i];
       tile[t][ty + 8 * i][2 * tx + 1] = s1[t][i];
     }
   }
   __syncthreads();
-  const int run = 32 * KW;
+  const int run = RB * KW;
   for (int e = threadIdx.x; e < 64 * run; e += 256) {
     const int cc = e / run, j = e - cc * run, mr = j / KW, tt = j - mr * KW;
     if (c0 + cc >= C || m0 + mr >= M) continue;
@@ -131,8 +135,8 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
 static inline void wgrad_reduce_launch(const float* partial, float* dw, int splits, int KW, int M, int C, int w_layout,
                                        int accumulate, hipStream_t s) {
   if (w_layout == ALVQ_W_IOK) {
-    const int grid = ((M + 31) / 32) * ((C + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_iok_kernel, dim3(grid), dim3(256), 0, s, partial, dw, splits, KW, M, C, accumulate);
+    const int grid = ((M + 15) / 16) * ((C + 63) / 64);
+    hipLaunchKernelGGL(wgrad_reduce_iok_kernel<16>, dim3(grid), dim3(256), 0, s, partial, dw, splits, KW, M, C, accumulate);
     return;
   }
   const long total = (long)KW * M * C;
