@@ -36,17 +36,21 @@ __global__ __launch_bounds__(THREADS) void rate_kernel(unsigned long long* stamp
     for (int j = 0; j < 2; ++j)
       for (int q = 0; q < 16; ++q) c[i][j][q] = 0.f;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-#define H(MI, NI, KS) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[MI][NI]) : "v"(ha[MODE == 4 ? MI : 0][KS]), "v"(hb[MODE == 4 ? NI : 0][KS]));
+#define H(MI, NI, KS) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[MI][NI]) : "v"(ha[MODE >= 4 ? MI : 0][KS]), "v"(hb[MODE >= 4 ? NI : 0][KS]));
 #define Q(MI, NI) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c[MI][NI]) : "v"(qa[MI]), "v"(qb[NI]), "v"(sa), "v"(sb));
 #define Q6(MI, NI) { const v6i a6 = __builtin_shufflevector(qa[MI], qa[MI], 0, 1, 2, 3, 4, 5), b6 = __builtin_shufflevector(qb[NI], qb[NI], 0, 1, 2, 3, 4, 5); \
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(c[MI][NI]) : "v"(a6), "v"(b6), "v"(sa), "v"(sb)); }
 #define ALL(X) X(0, 0) X(0, 1) X(1, 0) X(1, 1) X(2, 0) X(2, 1) X(3, 0) X(3, 1)
+#define SERP(X) X(0, 0) X(1, 0) X(2, 0) X(3, 0) X(3, 1) X(2, 1) X(1, 1) X(0, 1)   /* B-stationary serpentine */
 #define H0(MI, NI) H(MI, NI, 0)
 #define H1(MI, NI) H(MI, NI, 1)
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0 || MODE == 2 || MODE == 4) { ALL(H0) ALL(H1) }
     if (MODE == 1 || MODE == 2) { ALL(Q) }
     if (MODE == 3) { ALL(Q6) }
+    if (MODE == 5) { SERP(H0) SERP(H1) }
+    if (MODE == 6) { SERP(H0) SERP(H1) SERP(Q) }
+    if (MODE == 7) { ALL(H0) ALL(H1) ALL(Q) }
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -73,12 +77,12 @@ static void run(const char* name, int grid, int iters) {
   double cyc = 0, ref = 0;
   for (int i = 0; i < grid; ++i) { cyc += h[2 * i]; ref += h[2 * i + 1]; }
   cyc /= grid; ref /= grid;
-  const int per_iter = (MODE == 2) ? 24 : (MODE == 1 || MODE == 3) ? 8 : 16;
+  const int per_iter = (MODE == 2 || MODE == 6 || MODE == 7) ? 24 : (MODE == 1 || MODE == 3) ? 8 : 16;
   const int waves_per_simd = THREADS / 256;
   const double us = ref / 100.0;                      // s_memrealtime: 100 MHz
   const double mfma_per_simd = (double)iters * per_iter * waves_per_simd;
   // nominal pipe cycles: fp16 32, fp8 64, fp6 32
-  const double nominal = (MODE == 2) ? (16 * 32 + 8 * 64) / 24.0 : (MODE == 1) ? 64 : 32;
+  const double nominal = (MODE == 2 || MODE == 6 || MODE == 7) ? (16 * 32 + 8 * 64) / 24.0 : (MODE == 1) ? 64 : 32;
   printf("%-34s grid %4d waves/SIMD %d: %7.1f us  s_memtime/MFMA %6.2f  ns/MFMA %6.2f  => %5.2f GHz-equivalent of nominal %4.1f cycles  (event %.3f ms)\n",
          name, grid, waves_per_simd, us, cyc / mfma_per_simd, us * 1000.0 / mfma_per_simd, nominal / (us * 1000.0 / mfma_per_simd), nominal, ms);
   hipFree(st); hipFree(out); free(h);
@@ -92,6 +96,11 @@ int main() {
     run<1, 512>("fp8 MX 32x32x64", grid, iters);
     run<3, 512>("fp6 MX 32x32x64", grid, iters);
     run<2, 512>("K-tile mix: 16 fp16 + 8 fp8", grid, iters);
+    run<7, 512>("mix, 4A x 2B, row-major order", grid, iters);
+    run<6, 512>("mix, 4A x 2B, B-stationary order", grid, iters);
+    run<5, 512>("fp16, 4A x 2B, B-stationary order", grid, iters);
+    run<7, 512>("mix, 4A x 2B, row-major order", grid, iters);
+    run<6, 512>("mix, 4A x 2B, B-stationary order", grid, iters);
     run<0, 256>("fp16 32x32x16 (one fragment pair)", grid, iters);
     run<4, 256>("fp16 32x32x16 (4 A x 2 B fragments)", grid, iters);
     run<1, 256>("fp8 MX 32x32x64", grid, iters);
