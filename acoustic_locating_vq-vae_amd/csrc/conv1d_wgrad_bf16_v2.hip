@@ -15,6 +15,8 @@
 // lane group g takes rows {4g..4g+3} and {16+4g..16+4g+3} of the K-tile, identically for both operands, which a
 // contraction does not care about -- so each half-wave reads 8 CONSECUTIVE rows: 8 distinct segments, conflict free
 // for every tap offset.
+#include <stdlib.h>
+
 #include "alvq_common.h"
 #include "bf16_common.h"
 #include "wgrad_reduce.h"
@@ -285,6 +287,226 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
   }
 }
 
+// ------------------------------------------------------------------------------------ v3: 32x32 MFMAs, two fragment sets
+// The weight gradient without a fused bias gradient (the shared residual weights, i.e. the two largest launches of a
+// step per width) on the structure of the f16mx weight gradient (conv1d_wgrad_f16mx.hip) minus its fp8 half:
+// v_mfma_f32_32x32x16_bf16, transposing reads with rows of one parity per half-wave (conflict-free), XOR-factored
+// fragment addresses (one base register per operand and tap), tied asm MFMAs, LDS-DMA as asm.
+//   KW = 1: (NC, MF) = (2, 4): 256 m x 256 c per workgroup, a wave owns 128 x 64 -- half the LDS-DMA bytes per MFMA of
+//           the 128 x 256 tile above, which ran at a matrix-pipe utilisation of 0.33;
+//   KW = 3: (NC, MF) = (1, 2): 128 m x 128 c x 3 taps, a wave owns 64 x 32 x 3.
+// With no second phase to hide them in, the next K-tile's fragments are read into a SECOND register set while this
+// K-tile's MFMAs run, the ring is four stages deep (K-tile t+3 is requested at the top of K-tile t: two K-tiles of lead)
+// and there is one barrier per K-tile, after which K-tile t+1 is visible and the stage K-tile t-1 occupied is free.
+typedef __attribute__((address_space(3))) s16x4_t* v3_lds_tr_ptr;
+
+template <int KW, int NC, int MF>
+__global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v3_kernel(WgradV2Args a) {
+  constexpr int PAD = (KW - 1) / 2;
+  constexpr int MT = 2 * MF * 32, CT = 4 * NC * 32;
+  constexpr int YRB = MT * 2, XRB = CT * 2;
+  constexpr int XROWS = KW == 1 ? 32 : 36;
+  constexpr int YBYTES = 32 * YRB, XBYTES = XROWS * XRB;
+  constexpr int STAGE = YBYTES + XBYTES;
+  constexpr int XPIECES = XBYTES / 1024, XROWS_PER_PIECE = 1024 / XRB;
+  constexpr int YPIECES = YBYTES / 1024, YROWS_PER_PIECE = 1024 / YRB;
+  constexpr int PER_WAVE = YPIECES / 8 + XPIECES / 8;        // DMA pieces per K-tile of a wave without the extra one
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 2) * (MF * 32), wc0 = (wave & 3) * NC * 32;
+  const int ntile = a.mtiles * a.ctiles;
+  const int id = xcd_remap(blockIdx.x, ntile * a.splits);
+  const int split = id / ntile, t_id = id % ntile;
+  const int m0 = (t_id / a.ctiles) * MT, c0 = (t_id % a.ctiles) * CT;
+  const int vrows = a.nseg * a.total_rows;
+  const int rbeg = split * a.chunks_per_split * 64;
+  const int rend = min(vrows, rbeg + a.chunks_per_split * 64);
+  const int n = (rend - rbeg) / 32;
+
+  // ---- staging (as in the kernels above: 1-KB pieces, 32-byte segments swizzled by the row)
+  const int y_r = (lane * 16) / YRB, y_s = ((lane * 16) % YRB) >> 4;
+  const int x_r = (lane * 16) / XRB, x_s = ((lane * 16) % XRB) >> 4;
+  auto src_slot = [](int slot, int row) { return (slot & 16) | (((((slot >> 1) & 7) ^ (row & 7)) << 1) | (slot & 1)); };
+  const int last_row = a.total_rows - 1;
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds;
+  auto dma = [&](const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  };
+  const bool extra = (XPIECES % 8 != 0) && (wave < XPIECES % 8);   // this wave stages one more X piece per K-tile
+  int is_seg = rbeg / a.total_rows;
+  int is_row = rbeg - is_seg * a.total_rows;
+  auto issue = [&](int stage) {
+    const unsigned dst = lds0 + stage * STAGE;
+    const char* const dyp = (const char*)a.dy[is_seg];
+    const char* const xp = (const char*)a.x[is_seg];
+#pragma unroll
+    for (int q = 0; q < YPIECES / 8; ++q) {
+      const int p = wave + 8 * q;
+      const int lr = p * YROWS_PER_PIECE + y_r;
+      const int mcol = min(m0 + src_slot(y_s, lr) * 8, a.Mp - 8);
+      dma(dyp, (unsigned)(((long)(is_row + lr) * a.Mp + mcol) * 2), dst + p * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < (XPIECES + 7) / 8; ++q) {
+      const int p = wave + 8 * q;
+      if (p < XPIECES) {
+        const int lr = p * XROWS_PER_PIECE + x_r;
+        int gr = is_row - PAD + lr;
+        gr = gr < 0 ? 0 : (gr > last_row ? last_row : gr);
+        const int ccol = min(c0 + src_slot(x_s, lr) * 8, a.Cp - 8);
+        dma(xp, (unsigned)(((long)gr * a.Cp + ccol) * 2), dst + YBYTES + p * 1024);
+      }
+    }
+    is_row += 32;
+    if (is_row == a.total_rows) {
+      is_row = 0;
+      ++is_seg;
+    }
+  };
+  auto wait_keep = [&](int tiles) {      // leave the DMA of `tiles` K-tiles (0..2) of this wave outstanding
+    if (tiles == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (tiles == 1) {
+      if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+    } else {
+      if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE + 2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+    }
+  };
+
+  // ---- transposed fragment reads (lane geometry and swizzle of conv1d_wgrad_f16mx.hip)
+  const int i16 = lane & 15, blk = (lane >> 4) & 1, g = lane >> 5;
+  const int q4 = i16 >> 2, p4 = i16 & 3;
+  const int krow = 2 * q4 + g;
+  const int sA = wm0 >> 4, sB = wc0 >> 4;
+  const int aHb = krow * YRB + p4 * 8 + (sA >> 3) * 256 + ((((sA & 7) ^ blk) ^ (krow & 7)) << 5);
+  int bHb[KW];
+#pragma unroll
+  for (int t = 0; t < KW; ++t) bHb[t] = (krow + t) * XRB + p4 * 8 + (sB >> 3) * 256 + ((((sB & 7) ^ blk) ^ ((krow + t) & 7)) << 5);
+  bf16x8_t aF[2][MF][2], bF[2][KW][NC][2];       // [register set][...][k-step]
+#define V3_TR16(DST, OFF, ROWB)                                                                                    \
+  {                                                                                                                \
+    const s16x4_t lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v3_lds_tr_ptr)(lds + (OFF)));                    \
+    const s16x4_t hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v3_lds_tr_ptr)(lds + (OFF) + 16 * (ROWB)));      \
+    DST = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7));                 \
+  }
+#define V3_RD_A(SET, ST, MI, KS) V3_TR16(aF[SET][MI][KS], (ST) * STAGE + (aHb ^ ((MI) << 6)) + 8 * (KS) * YRB, YRB)
+#define V3_RD_B(SET, ST, TP, CF, KS) V3_TR16(bF[SET][TP][CF][KS], (ST) * STAGE + YBYTES + (bHb[TP] ^ ((CF) << 6)) + 8 * (KS) * XRB, XRB)
+#define V3_MM(SET, MI, TP, CF, KS) \
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[TP][MI][CF]) : "v"(aF[SET][MI][KS]), "v"(bF[SET][TP][CF][KS]));
+#define V3_SB __builtin_amdgcn_sched_barrier(0);
+
+  f32x16 acc[KW][MF][NC];
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+      for (int jn = 0; jn < NC; ++jn)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][i][jn][q] = 0.f;
+
+  // One K-tile held in register set SET; NS = the stage of the next K-tile, read into the other set meanwhile (two
+  // transposing reads in the shadow of one MFMA each, ordered by first use).  Written out per instantiation.
+#define V3_TILE_K1(SET, NS, MORE)                                                                                  \
+  V3_MM(SET, 0, 0, 0, 0) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 0, 0, 0) } V3_SB                                 \
+  V3_MM(SET, 0, 0, 1, 0) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 0, 0) } V3_SB                                    \
+  V3_MM(SET, 1, 0, 0, 0) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 0, 1, 0) } V3_SB                                 \
+  V3_MM(SET, 1, 0, 1, 0) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 1, 0) } V3_SB                                    \
+  V3_MM(SET, 2, 0, 0, 0) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 2, 0) } V3_SB                                    \
+  V3_MM(SET, 2, 0, 1, 0) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 3, 0) } V3_SB                                    \
+  V3_MM(SET, 3, 0, 0, 0) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 0, 0, 1) } V3_SB                                 \
+  V3_MM(SET, 3, 0, 1, 0) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 0, 1) } V3_SB                                    \
+  V3_MM(SET, 0, 0, 0, 1) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 0, 1, 1) } V3_SB                                 \
+  V3_MM(SET, 0, 0, 1, 1) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 1, 1) } V3_SB                                    \
+  V3_MM(SET, 1, 0, 0, 1) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 2, 1) } V3_SB                                    \
+  V3_MM(SET, 1, 0, 1, 1) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 3, 1) } V3_SB                                    \
+  V3_MM(SET, 2, 0, 0, 1) V3_MM(SET, 2, 0, 1, 1) V3_MM(SET, 3, 0, 0, 1) V3_MM(SET, 3, 0, 1, 1) V3_SB
+#define V3_TILE_K3(SET, NS, MORE)                                                                                  \
+  V3_MM(SET, 0, 0, 0, 0) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 0, 0, 0) } V3_SB                                 \
+  V3_MM(SET, 0, 1, 0, 0) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 0, 0) } V3_SB                                    \
+  V3_MM(SET, 0, 2, 0, 0) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 1, 0, 0) } V3_SB                                 \
+  V3_MM(SET, 1, 0, 0, 0) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 2, 0, 0) } V3_SB                                 \
+  V3_MM(SET, 1, 1, 0, 0) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 1, 0) } V3_SB                                    \
+  V3_MM(SET, 1, 2, 0, 0) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 0, 0, 1) } V3_SB                                 \
+  V3_MM(SET, 0, 0, 0, 1) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 0, 1) } V3_SB                                    \
+  V3_MM(SET, 0, 1, 0, 1) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 1, 0, 1) } V3_SB                                 \
+  V3_MM(SET, 0, 2, 0, 1) V3_SB if (MORE) { V3_RD_B((SET) ^ 1, NS, 2, 0, 1) } V3_SB                                 \
+  V3_MM(SET, 1, 0, 0, 1) V3_SB if (MORE) { V3_RD_A((SET) ^ 1, NS, 1, 1) } V3_SB                                    \
+  V3_MM(SET, 1, 1, 0, 1) V3_MM(SET, 1, 2, 0, 1) V3_SB
+#define V3_TILE(SET, NS, MORE) if constexpr (KW == 1) { V3_TILE_K1(SET, NS, MORE) } else { V3_TILE_K3(SET, NS, MORE) }
+
+  if (n > 0) {
+    issue(0);
+    if (n > 1) issue(1);
+    if (n > 2) issue(2);
+    wait_keep(n > 2 ? 2 : (n > 1 ? 1 : 0));      // K-tile 0 landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) { V3_RD_A(0, 0, mi, 0) V3_RD_A(0, 0, mi, 1) }
+#pragma unroll
+    for (int tp = 0; tp < KW; ++tp)
+#pragma unroll
+      for (int cf = 0; cf < NC; ++cf) { V3_RD_B(0, 0, tp, cf, 0) V3_RD_B(0, 0, tp, cf, 1) }
+    // K-tile t: its fragments are in set t & 1.  At the top: wait until K-tile t+1 has landed (K-tile t+2 may stay in
+    // flight), barrier (every wave has finished reading K-tile t's stage during K-tile t-1 -- and K-tile t-1's stage
+    // before that), request K-tile t+3 into the stage of K-tile t-1.
+#define V3_TOP(T)                                                                                                  \
+  if ((T) + 1 < n) {                                                                                               \
+    wait_keep((T) + 2 < n ? 1 : 0);                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    if ((T) + 3 < n) issue(((T) + 3) & 3);                                                                         \
+  } else {                                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+  }
+    for (int t = 0; t < n; t += 4) {       // n is even; four K-tiles per iteration so that stage indices are constants
+      V3_TOP(t)
+      V3_TILE(0, 1, t + 1 < n)
+      V3_TOP(t + 1)
+      V3_TILE(1, 2, t + 2 < n)
+      if (t + 2 < n) {
+        V3_TOP(t + 2)
+        V3_TILE(0, 3, t + 3 < n)
+        V3_TOP(t + 3)
+        V3_TILE(1, 0, t + 4 < n)
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA-result -> VALU-read wait states (asm MFMAs are invisible)
+  }
+#undef V3_TOP
+#undef V3_TILE
+#undef V3_TILE_K3
+#undef V3_TILE_K1
+#undef V3_SB
+#undef V3_MM
+#undef V3_RD_B
+#undef V3_RD_A
+#undef V3_TR16
+
+  // ---- partial[split][t][m][c] (fp32); D[i = m][j = c]: lane (j = lane & 31, g), register q holds m = (q & 3) + 8 (q >> 2) + 4 g
+  const int jc = lane & 31;
+  float* out = a.partial + (long)split * KW * a.M * a.C;
+#pragma unroll
+  for (int t = 0; t < KW; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+      for (int cf = 0; cf < NC; ++cf)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m0 + wm0 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * g;
+          const int c = c0 + wc0 + cf * 32 + jc;
+          if (m < a.M && c < a.C) out[((long)t * a.M + m) * a.C + c] = acc[t][mi][cf][q];
+        }
+}
+
+template <int KW, int NC, int MF>
+static constexpr int wgrad_v3_lds() {
+  return 4 * (32 * (2 * MF * 32 * 2) + (KW == 1 ? 32 : 36) * (4 * NC * 32 * 2));
+}
+
 // dbias[m] (+)= sum_s bias_partial[s][m], fixed order
 static __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* bp, float* dbias, int splits, int Mp, int M,
                                                                        int accumulate) {
@@ -315,9 +537,16 @@ int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int K
   const int ct = KW == 3 ? 128 : 256;
   const int tiles = ((M + 127) / 128) * ((C + ct - 1) / ct);
   int cps;
-  const int splits = wgrad_v2_splits(WG_MAXSEG * total_rows, tiles, &cps);   // the split count never exceeds this
+  int splits = wgrad_v2_splits(WG_MAXSEG * total_rows, tiles, &cps);   // the split count never exceeds this
   const int splits1 = wgrad_v2_splits(total_rows, tiles, &cps);
-  return (int64_t)(splits > splits1 ? splits : splits1) * KW * M * C * 4;
+  if (splits1 > splits) splits = splits1;
+  if (KW == 1) {     // the 256 x 256 kernel has fewer tiles, hence more splits
+    const int tiles_k1 = ((M + 255) / 256) * ((C + 255) / 256);
+    const int sk = wgrad_v2_splits(WG_MAXSEG * total_rows, tiles_k1, &cps), sk1 = wgrad_v2_splits(total_rows, tiles_k1, &cps);
+    if (sk > splits) splits = sk;
+    if (sk1 > splits) splits = sk1;
+  }
+  return (int64_t)splits * KW * M * C * 4;
 }
 
 int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
@@ -335,14 +564,22 @@ int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int
   a.Mp = Mp; a.Cp = Cp; a.M = M; a.C = C;
   a.mtiles = (M + 127) / 128; a.ctiles = (C + ct - 1) / ct;
   a.total_rows = total_rows; a.nseg = nseg;
+  // no bias gradient (the shared residual weights): the v3 kernels.  ALVQ_WGRAD_V3 = 0 none, 1 width 1 only, 3 (default) both.
+  const int v3_sel = getenv("ALVQ_WGRAD_V3") ? atoi(getenv("ALVQ_WGRAD_V3")) : 3;
+  const bool v3 = !dbias && ((KW == 1 && (v3_sel & 1)) || (KW == 3 && (v3_sel & 2)));
+  if (v3 && KW == 1) a.mtiles = (M + 255) / 256;
   a.splits = wgrad_v2_splits(nseg * total_rows, a.mtiles * a.ctiles, &a.chunks_per_split);
   static DeviceOnce attr;
   if (attr.need()) {
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v3_kernel<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v3_lds<1, 2, 4>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v3_kernel<3, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v3_lds<3, 1, 2>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<3, 2>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<1, 4>());
   }
   const int grid = a.mtiles * a.ctiles * a.splits;
-  if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<3, 2>), dim3(grid), dim3(512), (wgrad_v2_lds<3, 2>()), s, a);
+  if (v3 && KW == 1) hipLaunchKernelGGL((conv1d_wgrad_bf16_v3_kernel<1, 2, 4>), dim3(grid), dim3(512), (wgrad_v3_lds<1, 2, 4>()), s, a);
+  else if (v3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v3_kernel<3, 1, 2>), dim3(grid), dim3(512), (wgrad_v3_lds<3, 1, 2>()), s, a);
+  else if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<3, 2>), dim3(grid), dim3(512), (wgrad_v2_lds<3, 2>()), s, a);
   else hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<1, 4>), dim3(grid), dim3(512), (wgrad_v2_lds<1, 4>()), s, a);
   int rc = check_launch("alvq_conv1d_wgrad_bf16(v2)");
   if (rc) return rc;
