@@ -59,6 +59,8 @@ def test_fuzz_bf16(B, C, M, L, KW, planes, tol):
     assert rel(N.conv1d_bf16(dyn, N.pack_weight(wd, N.W_IOK, planes), out_ncl=True), x.grad) < tol
     dw, db = N.conv1d_wgrad_bf16(dyn, xn, KW, want_bias=True)
     assert rel(dw, w.grad) < 2 * tol
+    # without a bias gradient the bf16 launch takes the 32x32-MFMA kernels (256 x 256 tile for width 1)
+    assert rel(N.conv1d_wgrad_bf16(dyn, xn, KW), w.grad) < 2 * tol
     # column sums of dy as stored: exact bf16 values (planes = 1) or hi + lo pairs carrying 2^-17 of each element
     assert float((db.cpu() - b.grad).abs().max()) <= (2e-6 if planes == 1 else 2e-5) * float(dy.abs().sum(dim=(0, 2)).max()) + 1e-30
     # the bf16 NLC output keeps its gap / tail rows and padded channels at zero for any shape
