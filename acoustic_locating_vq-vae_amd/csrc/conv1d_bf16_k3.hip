@@ -12,9 +12,9 @@
 //           are fetched from the other stage meanwhile)
 // Part A = the weight slabs of taps 0 and 1 (4 DMA pieces per wave), part B = tap 2's weights and the activation
 // slab (4 pieces, wave 7 one more for the two halo rows).  One barrier per 96 MFMAs; every DMA piece has more than
-// a full tap phase to land.  LDS rows are 64 B with the v2 slot swizzle (slot = group ^ {0,3,2,1}[(row>>2)&3]) on
-// weights and activations alike; the shifted activation reads of taps 1 and 2 see a 2-way conflict on two of the
-// sixteen 16-lane bank groups, which costs a few cycles per phase.
+// a full tap phase to land.  LDS rows are 64 B; the weight slabs carry the v2 slot swizzle (slot = group ^
+// {0,3,2,1}[(row>>2)&3]), the activation slab one that stays conflict-free when read 1 or 2 rows further down
+// (slot = group ^ {0,2,0,2}[(row>>2)&3], derivation at lane_off_x below).
 #include <stdlib.h>
 
 #include "alvq_common.h"
@@ -50,11 +50,22 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_k3_kernel(ConvBArgs a) {
   // goes into the instruction's SGPR base.  Written as inline asm: through the builtin, hipcc hoists
   // (lane offset + k * 16 rows) into five loop-invariant 64-bit VGPR pairs, which this kernel has no room for.
   const unsigned lane_off = (unsigned)(srow * Cp + sgrp * 8) * 2u;
+  // The ACTIVATION slab uses its own slot swizzle, slot = group ^ {0,2,0,2}[(row>>2)&3]: the taps read it at row
+  // offsets 0, 1, 2, and under the weight slabs' {0,3,2,1} the shifted reads collide two-fold in two of every sixteen
+  // lanes of a ds_read_b128 bank group (18 % of this kernel's LDS cycles were conflicts).  A 16-lane group takes four
+  // row quads with channel groups (a, b, b, a), b = a ^ 1; rows shifted across a quad boundary keep their lane's group
+  // but take the next quad's key, so the key f must make both {f0, f3, f1^1, f2^1} and {f0, f1, f2^1, f3^1}
+  // permutations of 0..3 -- (0, 2, 0, 2) does, (0, 3, 2, 1) only the first.
+  const unsigned lane_off_x = (unsigned)(srow * Cp + ((lane & 3) ^ ((hsel & 1) * 2)) * 8) * 2u;
   const long tap_w = (long)a.Mp128 * Cp;
   const long row16 = (long)Cp * 32;                            // bytes per 16 rows
   const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) unsigned char*)lds);
   auto dma = [&](const char* sbase, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+  };
+  auto dma_x = [&](const char* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off_x), "s"(sbase), "s"(lds_dst)
                  : "memory");
   };
   // part A: waves 0-3 stage tap 0, waves 4-7 tap 1; 64 weight rows (4 pieces) each
@@ -79,9 +90,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_k3_kernel(ConvBArgs a) {
     const char* xs = xB + c * (V2_K * 2);
     dma(ws, st + dBw);
     dma(ws + row16, st + dBw + 1024);
-    dma(xs, st + dBx);
-    dma(xs + row16, st + dBx + 1024);
-    if (wave == 7 && srow < 2) dma(xs + 2 * row16, st + dBx + 2048);   // halo: slab rows 256, 257
+    dma_x(xs, st + dBx);
+    dma_x(xs + row16, st + dBx + 1024);
+    if (wave == 7 && srow < 2) dma_x(xs + 2 * row16, st + dBx + 2048);   // halo: slab rows 256, 257
   };
 
   // ---- fragment read addressing: weights as in v2; activations per tap (slab row = local row + tap)
@@ -90,8 +101,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_k3_kernel(ConvBArgs a) {
   int loffX[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    const int r = li + t, h = (r >> 2) & 3;
-    loffX[t] = r * 64 + ((kq ^ (h == 0 ? 0 : 4 - h)) << 4);
+    const int r = li + t;
+    loffX[t] = r * 64 + ((kq ^ (((r >> 2) & 1) * 2)) << 4);
   }
   const unsigned char* const abase = lds + wm0 * 64 + loffA;
   const unsigned char* const xbase = lds + 3 * V2_HALF + wn0 * 64;
