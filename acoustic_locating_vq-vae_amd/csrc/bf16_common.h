@@ -118,12 +118,15 @@ __device__ __forceinline__ void epilogue_store8(const ConvBArgs& a, float (&v)[8
   *(u32x4*)(a.y + o) = out;
   if (a.y2) *(u32x4*)(a.y2 + o) = out2;
   if (a.bits_out) {   // bit e = (stored y[e] > 0); zero for gap / tail rows
+    // a bf16 in the upper half of a word IS the fp32 pattern of its value: positive and non-zero <=> that word > 0 as
+    // an integer.  t = max(word, 0) also disposes of -0; the sign of 0 - t is the bit, shifted in from the right by
+    // v_alignbit_b32 -- four VALU instructions per element instead of the dozen of the mask-and-compare form.
     unsigned bt = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned w = out[e];
-      bt |= (((w & 0x8000u) == 0 && (w & 0x7fffu) != 0) ? 1u : 0u) << (2 * e);
-      bt |= (((w & 0x80000000u) == 0 && (w & 0x7fff0000u) != 0) ? 1u : 0u) << (2 * e + 1);
+    for (int e = 7; e >= 0; --e) {
+      const int half = (int)((e & 1) ? (out[e >> 1] & 0xffff0000u) : (out[e >> 1] << 16));
+      const int t = half > 0 ? half : 0;
+      bt = __builtin_amdgcn_alignbit(bt, 0u - (unsigned)t, 31);
     }
     a.bits_out[o >> 3] = (unsigned char)bt;
   }
