@@ -77,61 +77,6 @@ __device__ __forceinline__ unsigned f2bf_pk(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
 }
 
-// Fused epilogue for 8 consecutive output channels of one row (both conv kernels): v = acc (+bias) (+skip1)
-// (+skip2); relu; mask; y = bf16(v); y2 = bf16(v + post).  Gap / tail rows are written as zeros.
-__device__ __forceinline__ void epilogue_store8(const ConvBArgs& a, float (&v)[8], const float (&bv)[8], bool ok, long o) {
-  u32x4 out = {0u, 0u, 0u, 0u}, out2 = {0u, 0u, 0u, 0u};
-  if (ok) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bv[e];
-    if (a.skip1) {
-      const u16x8 s = *(const u16x8*)(a.skip1 + o);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bf2f(s[e]);
-    }
-    if (a.skip2) {
-      const u16x8 s = *(const u16x8*)(a.skip2 + o);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bf2f(s[e]);
-    }
-    if (a.relu & 1) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    if (a.mask_bits) {
-      const unsigned bt = a.mask_bits[o >> 3];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ((bt >> e) & 1u) ? v[e] : 0.f;
-    } else if (a.mask) {
-      const u16x8 s = *(const u16x8*)(a.mask + o);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) out[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
-    if (a.y2) {
-      const u16x8 s = *(const u16x8*)(a.post + o);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) out2[e] = f2bf_pk(v[2 * e] + bf2f(s[2 * e]), v[2 * e + 1] + bf2f(s[2 * e + 1]));
-    }
-  }
-  *(u32x4*)(a.y + o) = out;
-  if (a.y2) *(u32x4*)(a.y2 + o) = out2;
-  if (a.bits_out) {   // bit e = (stored y[e] > 0); zero for gap / tail rows
-    // a bf16 in the upper half of a word IS the fp32 pattern of its value: positive and non-zero <=> that word > 0 as
-    // an integer.  t = max(word, 0) also disposes of -0; the sign of 0 - t is the bit, shifted in from the right by
-    // v_alignbit_b32 -- four VALU instructions per element instead of the dozen of the mask-and-compare form.
-    unsigned bt = 0;
-#pragma unroll
-    for (int e = 7; e >= 0; --e) {
-      const int half = (int)((e & 1) ? (out[e >> 1] & 0xffff0000u) : (out[e >> 1] << 16));
-      const int t = half > 0 ? half : 0;
-      bt = __builtin_amdgcn_alignbit(bt, 0u - (unsigned)t, 31);
-    }
-    a.bits_out[o >> 3] = (unsigned char)bt;
-  }
-}
-
 // defined in conv1d_bf16_v2.hip: the 256x256-tile kernel for wide layers
 int conv1d_bf16_v2_launch(const ConvBArgs& a, int KW, hipStream_t stream);
 // defined in conv1d_bf16_k3.hip: the same tile for width 3, one activation slab shared by the three taps

@@ -69,35 +69,105 @@ __device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4
   }
 }
 
+// Written for few VALU instructions per value -- the epilogue of a 256 x 256 tile is 16 of these 8-channel groups per
+// lane, and at ~100 instructions each it took twice the time its 2 bytes per element need on the way to HBM (measured by
+// compiling it out: 13 us of a width-3 launch's 86 us per round, 10 of a width-1 launch's 41):
+//  * a row block's pointers are formed once, the groups add constants to them;
+//  * nothing is computed for operands that are absent (no bias -> no bias vector of zeros to add);
+//  * gap / tail rows (one 16-row block in thirty holds one) are zeroed by a select on the four packed output words,
+//    inside a wave-uniform branch, instead of a divergent branch around the whole group;
+//  * the bias of a group that lies inside M is two 16-byte loads.
 template <int NMI, int NNI>
 __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[NMI][NNI], int m0, int r0, int li,
                                                    int kq, int wm0, int wn0) {
   static_assert(NMI % 2 == 0, "fragments are swapped in pairs");
-  {
-    const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  const int mb0 = m0 + wm0 + (kq & 1) * 16 + (kq >> 1) * 8;      // this lane's 8 channels of fragment pair 0
 #pragma unroll
-    for (int ni = 0; ni < NNI; ++ni) {
-      const int row = r0 + wn0 + ni * 16 + li;
-      int b, l;
-      const bool ok = row_valid(row, Lp1, ndata, &b, &l);
-      const long ro = (long)row * a.Mop;
+  for (int ni = 0; ni < NNI; ++ni) {
+    const int row = r0 + wn0 + ni * 16 + li;
+    int b, l;
+    const bool ok = row_valid(row, Lp1, ndata, &b, &l);
+    const bool gaps = !__all(ok);
+    const long o0 = (long)row * a.Mop + mb0;                      // element offset of the lane's first group
 #pragma unroll
-      for (int mp = 0; mp < NMI; mp += 2) {
-        if (m0 + wm0 + mp * 16 >= a.Mop) continue;      // Mop % 64 == 0 and the pair starts on a multiple of 32
-        float v[8];
+    for (int mp = 0; mp < NMI; mp += 2) {
+      if (m0 + wm0 + mp * 16 >= a.Mop) continue;        // Mop % 64 == 0 and the pair starts on a multiple of 32
+      const long o = o0 + mp * 16;
+      const int mb = mb0 + mp * 16;
+      float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // odd rows (of 16 lanes) of the first operand <-> even rows of the second
-          const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mp][ni][e]), __float_as_uint(acc[mp + 1][ni][e]),
-                                                           false, false);
-          v[e] = __uint_as_float(r[0]);
-          v[e + 4] = __uint_as_float(r[1]);
+      for (int e = 0; e < 4; ++e) {
+        // odd rows (of 16 lanes) of the first operand <-> even rows of the second
+        const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mp][ni][e]), __float_as_uint(acc[mp + 1][ni][e]),
+                                                         false, false);
+        v[e] = __uint_as_float(r[0]);
+        v[e + 4] = __uint_as_float(r[1]);
+      }
+      if (a.bias) {
+        if (m0 + wm0 + mp * 16 + 32 <= a.M) {
+          const f32x4 b0 = *(const f32x4*)(a.bias + mb), b1 = *(const f32x4*)(a.bias + mb + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += b0[e];
+            v[4 + e] += b1[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (mb + e < a.M) ? a.bias[mb + e] : 0.f;
         }
-        const int mb = m0 + wm0 + (mp + (kq & 1)) * 16 + (kq >> 1) * 8;
-        float bv[8];
+      }
+      if (a.skip1) {
+        const u16x8 sk = *(const u16x8*)(a.skip1 + o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (a.bias && mb + e < a.M) ? a.bias[mb + e] : 0.f;
-        epilogue_store8(a, v, bv, ok, ro + mb);
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(sk[e]);
+      }
+      if (a.skip2) {
+        const u16x8 sk = *(const u16x8*)(a.skip2 + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(sk[e]);
+      }
+      if (a.relu & 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (a.mask_bits) {     // sign-extend bit e to a word and AND
+        const int bt = (int)a.mask_bits[o >> 3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (unsigned)((bt << (31 - e)) >> 31));
+      } else if (a.mask) {
+        const u16x8 mk = *(const u16x8*)(a.mask + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(mk[e]) > 0.f ? v[e] : 0.f;
+      }
+      u32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
+      if (gaps) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = ok ? out[e] : 0u;
+      }
+      *(u32x4*)(a.y + o) = out;
+      if (a.y2) {
+        const u16x8 ps = *(const u16x8*)(a.post + o);
+        u32x4 out2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out2[e] = f2bf_pk(v[2 * e] + bf2f(ps[2 * e]), v[2 * e + 1] + bf2f(ps[2 * e + 1]));
+        if (gaps) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out2[e] = ok ? out2[e] : 0u;
+        }
+        *(u32x4*)(a.y2 + o) = out2;
+      }
+      if (a.bits_out) {   // bit e = (stored y[e] > 0): a bf16 in the upper half of a word is the fp32 pattern of its value
+        unsigned bt = 0;
+#pragma unroll
+        for (int e = 7; e >= 0; --e) {
+          const int half = (int)((e & 1) ? (out[e >> 1] & 0xffff0000u) : (out[e >> 1] << 16));
+          const int t = half > 0 ? half : 0;
+          bt = __builtin_amdgcn_alignbit(bt, 0u - (unsigned)t, 31);
+        }
+        a.bits_out[o >> 3] = (unsigned char)bt;
       }
     }
   }
