@@ -90,6 +90,17 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
     const bool ok = row_valid(row, Lp1, ndata, &b, &l);
     const bool gaps = !__all(ok);
     const long o0 = (long)row * a.Mop + mb0;                      // element offset of the lane's first group
+    // the skip / mask operands of the whole row block are requested before the first group is finished (a load ->
+    // wait -> use chain per group is one L2 / HBM round trip each, sixteen per lane)
+    u16x8 s1[NMI / 2], s2[NMI / 2], mk[NMI / 2];
+#pragma unroll
+    for (int mp = 0; mp < NMI; mp += 2) {
+      if (m0 + wm0 + mp * 16 >= a.Mop) continue;
+      if (a.skip1) s1[mp / 2] = *(const u16x8*)(a.skip1 + o0 + mp * 16);
+      if (a.skip2) s2[mp / 2] = *(const u16x8*)(a.skip2 + o0 + mp * 16);
+      if (a.mask && !a.mask_bits) mk[mp / 2] = *(const u16x8*)(a.mask + o0 + mp * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mp = 0; mp < NMI; mp += 2) {
       if (m0 + wm0 + mp * 16 >= a.Mop) continue;        // Mop % 64 == 0 and the pair starts on a multiple of 32
@@ -118,14 +129,12 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
         }
       }
       if (a.skip1) {
-        const u16x8 sk = *(const u16x8*)(a.skip1 + o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bf2f(sk[e]);
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(s1[mp / 2][e]);
       }
       if (a.skip2) {
-        const u16x8 sk = *(const u16x8*)(a.skip2 + o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bf2f(sk[e]);
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(s2[mp / 2][e]);
       }
       if (a.relu & 1) {
 #pragma unroll
@@ -136,9 +145,8 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (unsigned)((bt << (31 - e)) >> 31));
       } else if (a.mask) {
-        const u16x8 mk = *(const u16x8*)(a.mask + o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(mk[e]) > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(mk[mp / 2][e]) > 0.f ? v[e] : 0.f;
       }
       u32x4 out;
 #pragma unroll
