@@ -35,38 +35,49 @@ __device__ __forceinline__ void split2(float v, u16& hi, u16& lo) {
   lo = f2bf(v - bf2f(hi));
 }
 
-// 8 consecutive channels of one row: two 16-byte stores per output (hi and lo plane), hardware bf16 rounding
-__device__ __forceinline__ void split_store8(u16* p, long plane, long o, const float (&v)[8]) {
-  u32x4 hi, lo;
+// 8 consecutive channels of one row -> packed hi and lo words (hardware bf16 rounding)
+__device__ __forceinline__ void split_pack8(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     hi[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
     lo[e] = f2bf_pk(v[2 * e] - __uint_as_float(hi[e] << 16), v[2 * e + 1] - __uint_as_float(hi[e] & 0xffff0000u));
   }
-  *(u32x4*)(p + o) = hi;
-  *(u32x4*)(p + plane + o) = lo;
-}
-__device__ __forceinline__ void split_load_add8(const u16* p, long plane, long o, float (&v)[8]) {
-  const u16x8 sh = *(const u16x8*)(p + o), sl = *(const u16x8*)(p + plane + o);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] += bf2f(sh[e]) + bf2f(sl[e]);
 }
 
 // Register-direct epilogue of one wave's 128 (m) x 64 (rows) block, split-bf16 flavour of wave_epilogue_bf16
-// (conv1d_bf16_tile256.h): v_permlane16_swap gives every lane 8 consecutive channels, 16-byte loads and stores.
+// (conv1d_bf16_tile256.h): v_permlane16_swap gives every lane 8 consecutive channels, 16-byte loads and stores.  Written,
+// like that one, for few VALU instructions per value: a row block's offset is formed once, the skip / mask operands of
+// the whole row block are requested before the first group is finished, nothing is computed for absent operands, gap
+// rows are zeroed by a select on the packed words inside a wave-uniform branch.
 __device__ __forceinline__ void wave_epilogue_x3(const ConvX3Args& ax, const f32x4 (&acc)[8][4], int m0, int r0, int li,
                                                  int kq, int wm0, int wn0) {
   const ConvBArgs& a = ax.b;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
+  const int mb0 = m0 + wm0 + (kq & 1) * 16 + (kq >> 1) * 8;
+  const long pl = ax.y_plane;
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     const int row = r0 + wn0 + ni * 16 + li;
     int b, l;
     const bool ok = row_valid(row, Lp1, ndata, &b, &l);
-    const long ro = (long)row * a.Mop;
+    const bool gaps = !__all(ok);
+    const long o0 = (long)row * a.Mop + mb0;
+    u16x8 s1h[4], s1l[4], mk[4];
 #pragma unroll
     for (int mp = 0; mp < 8; mp += 2) {
       if (m0 + wm0 + mp * 16 >= a.Mop) continue;
+      if (a.skip1) {
+        s1h[mp / 2] = *(const u16x8*)(a.skip1 + o0 + mp * 16);
+        s1l[mp / 2] = *(const u16x8*)(a.skip1 + pl + o0 + mp * 16);
+      }
+      if (a.mask) mk[mp / 2] = *(const u16x8*)(a.mask + o0 + mp * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mp = 0; mp < 8; mp += 2) {
+      if (m0 + wm0 + mp * 16 >= a.Mop) continue;
+      const long o = o0 + mp * 16;
+      const int mb = mb0 + mp * 16;
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -75,31 +86,61 @@ __device__ __forceinline__ void wave_epilogue_x3(const ConvX3Args& ax, const f32
         v[e] = __uint_as_float(r[0]);
         v[e + 4] = __uint_as_float(r[1]);
       }
-      const int mb = m0 + wm0 + (mp + (kq & 1)) * 16 + (kq >> 1) * 8;
-      const long o = ro + mb;
-      float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (!ok) {                                           // gap / tail rows stay zero in both planes
-        split_store8(a.y, ax.y_plane, o, z);
-        if (a.y2) split_store8(a.y2, ax.y_plane, o, z);
-        continue;
-      }
+      if (a.bias) {
+        if (m0 + wm0 + mp * 16 + 32 <= a.M) {
+          const f32x4 b0 = *(const f32x4*)(a.bias + mb), b1 = *(const f32x4*)(a.bias + mb + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += (a.bias && mb + e < a.M) ? a.bias[mb + e] : 0.f;
-      if (a.skip1) split_load_add8(a.skip1, ax.y_plane, o, v);
-      if (a.skip2) split_load_add8(a.skip2, ax.y_plane, o, v);
+          for (int e = 0; e < 4; ++e) {
+            v[e] += b0[e];
+            v[4 + e] += b1[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (mb + e < a.M) ? a.bias[mb + e] : 0.f;
+        }
+      }
+      if (a.skip1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(s1h[mp / 2][e]) + bf2f(s1l[mp / 2][e]);
+      }
+      if (a.skip2) {
+        const u16x8 sh = *(const u16x8*)(a.skip2 + o), sl = *(const u16x8*)(a.skip2 + pl + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(sh[e]) + bf2f(sl[e]);
+      }
       if (a.relu & 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if (a.mask) {   // sign of a split value is the sign of its hi plane
-        const u16x8 s = *(const u16x8*)(a.mask + o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]) > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(mk[mp / 2][e]) > 0.f ? v[e] : 0.f;
       }
-      split_store8(a.y, ax.y_plane, o, v);
+      u32x4 hi, lo;
+      split_pack8(v, hi, lo);
+      if (gaps) {                                           // gap / tail rows stay zero in both planes
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = ok ? hi[e] : 0u;
+          lo[e] = ok ? lo[e] : 0u;
+        }
+      }
+      *(u32x4*)(a.y + o) = hi;
+      *(u32x4*)(a.y + pl + o) = lo;
       if (a.y2) {
-        split_load_add8(a.post, ax.y_plane, o, v);
-        split_store8(a.y2, ax.y_plane, o, v);
+        const u16x8 ph = *(const u16x8*)(a.post + o), pq = *(const u16x8*)(a.post + pl + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(ph[e]) + bf2f(pq[e]);
+        split_pack8(v, hi, lo);
+        if (gaps) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hi[e] = ok ? hi[e] : 0u;
+            lo[e] = ok ? lo[e] : 0u;
+          }
+        }
+        *(u32x4*)(a.y2 + o) = hi;
+        *(u32x4*)(a.y2 + pl + o) = lo;
       }
     }
   }
