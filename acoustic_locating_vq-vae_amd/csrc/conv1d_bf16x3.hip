@@ -344,9 +344,13 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
 }
 
 // ------------------------------------------------------------------------------------------- weight-gradient
+constexpr int WX_MAXSEG = 4;
 struct WgradX3Args {
-  const u16* dy;
-  const u16* x;
+  // Up to WX_MAXSEG (dy, x) pairs of identical shape whose products are summed into ONE dW (the R uses of a shared
+  // residual weight): virtual row v = seg * total_rows + r, as in the bf16 and f16mx weight gradients.
+  const u16* dy[WX_MAXSEG];
+  const u16* x[WX_MAXSEG];
+  int nseg;
   float* partial;
   float* bias_partial;   // [splits][Mp] column sums of dY (the bias gradient), or null
   long dy_plane, x_plane;
@@ -384,8 +388,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
   const int id = xcd_remap(blockIdx.x, ntile * a.splits);
   const int split = id / ntile, t_id = id % ntile;
   const int m0 = (t_id / a.ctiles) * MT, c0 = (t_id % a.ctiles) * CT;
+  const int vrows = a.nseg * a.total_rows;
   const int rbeg = split * a.chunks_per_split * 64;
-  const int rend = min(a.total_rows, rbeg + a.chunks_per_split * 64);
+  const int rend = min(vrows, rbeg + a.chunks_per_split * 64);
   const int n = (rend - rbeg) / 32;
 
   const int y_r = lane >> 4, y_s = lane & 15;
@@ -398,13 +403,14 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
   auto dma = [&](const char* sbase, unsigned voff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
   };
-  const char* const dy_hi = (const char*)a.dy;
-  const char* const dy_lo = (const char*)(a.dy + a.dy_plane);
-  const char* const x_hi = (const char*)a.x;
-  const char* const x_lo = (const char*)(a.x + a.x_plane);
-  int is_row = rbeg;
+  int is_seg = rbeg / a.total_rows;          // segment and first row (inside it) of the K-tile the next issue() stages
+  int is_row = rbeg - is_seg * a.total_rows;
   auto issue = [&](int stage) {
     const unsigned dst = lds0 + stage * STAGE;
+    const char* const dy_hi = (const char*)a.dy[is_seg];
+    const char* const dy_lo = (const char*)(a.dy[is_seg] + a.dy_plane);
+    const char* const x_hi = (const char*)a.x[is_seg];
+    const char* const x_lo = (const char*)(a.x[is_seg] + a.x_plane);
     {
       const int lr = 4 * wave + y_r;
       const int mcol = min(m0 + src_slot(y_s, lr) * 8, a.Mp - 8);
@@ -426,6 +432,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16x3_kernel(WgradX3Args
       }
     }
     is_row += 32;
+    if (is_row == a.total_rows) {
+      is_row = 0;
+      ++is_seg;
+    }
   };
 
   const int g = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
@@ -766,23 +776,32 @@ extern "C" int64_t alvq_conv1d_wgrad_bf16x3_workspace_bytes(int B, int C, int M,
   if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3)) return -1;
   const int rows = (int)alvq_nlc_rows(B, L);
   const int ct = KW == 3 ? 128 : 256;
+  const int tiles = ((M + 127) / 128) * ((C + ct - 1) / ct);
   int cps;
-  const int splits = wgrad_x3_splits(rows, ((M + 127) / 128) * ((C + ct - 1) / ct), &cps);
+  int splits = wgrad_x3_splits(rows, tiles, &cps);
+  const int splits_multi = wgrad_x3_splits(WX_MAXSEG * rows, tiles, &cps);   // the split count never exceeds this
+  if (splits_multi > splits) splits = splits_multi;
   return (int64_t)splits * KW * M * C * 4 + (int64_t)X3_BIAS_SPLITS * pad_to(M, 64) * 4;
 }
 
-extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C,
-                                        int M, int L, int KW, int w_layout, int accumulate, void* stream) {
-  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: null pointer");
-  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: bad dims");
-  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16x3: KW=%d (only 1 and 3)", KW);
-  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: w_layout");
-  hipStream_t s = (hipStream_t)stream;
+static int wgrad_x3_launch(const void* const* dy, const void* const* x, int nseg, float* dw, float* dbias, void* workspace, int B,
+                           int C, int M, int L, int KW, int w_layout, int accumulate, hipStream_t s) {
   const int rows = (int)alvq_nlc_rows(B, L);
   const int ct = KW == 3 ? 128 : 256;
-  WgradX3Args a{(const u16*)dy, (const u16*)x, (float*)workspace, nullptr, nlc_plane_elems(B, L, M), nlc_plane_elems(B, L, C),
-                pad_to(M, 64), pad_to(C, 64), M, C, (M + 127) / 128, (C + ct - 1) / ct, 0, 0, rows};
-  a.splits = wgrad_x3_splits(rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  WgradX3Args a{};
+  for (int i = 0; i < WX_MAXSEG; ++i) {
+    a.dy[i] = (const u16*)dy[i < nseg ? i : 0];
+    a.x[i] = (const u16*)x[i < nseg ? i : 0];
+  }
+  a.nseg = nseg;
+  a.partial = (float*)workspace;
+  a.bias_partial = nullptr;
+  a.dy_plane = nlc_plane_elems(B, L, M);
+  a.x_plane = nlc_plane_elems(B, L, C);
+  a.Mp = pad_to(M, 64); a.Cp = pad_to(C, 64); a.M = M; a.C = C;
+  a.mtiles = (M + 127) / 128; a.ctiles = (C + ct - 1) / ct;
+  a.total_rows = rows;
+  a.splits = wgrad_x3_splits(nseg * rows, a.mtiles * a.ctiles, &a.chunks_per_split);
   float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
   if (dbias) a.bias_partial = bpart;
   static DeviceOnce attr;
@@ -796,8 +815,28 @@ extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw
   int rc = check_launch("alvq_conv1d_wgrad_bf16x3");
   if (rc) return rc;
   wgrad_reduce_launch((const float*)workspace, dw, a.splits, KW, M, C, w_layout, accumulate, s);
-  if (dbias)
+  if (dbias)     // single segment only (the shared residual weights have no bias)
     hipLaunchKernelGGL(wgrad_x3_bias_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, a.splits,
                        a.Mp, M, accumulate);
   return check_launch("alvq_conv1d_wgrad_bf16x3/reduce");
+}
+
+extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C,
+                                        int M, int L, int KW, int w_layout, int accumulate, void* stream) {
+  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16x3: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: w_layout");
+  return wgrad_x3_launch(&dy, &x, 1, dw, dbias, workspace, B, C, M, L, KW, w_layout, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int alvq_conv1d_wgrad_bf16x3_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                              int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream) {
+  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3_multi: null pointer");
+  ALVQ_REQUIRE(nseg >= 1 && nseg <= WX_MAXSEG, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16x3_multi: nseg=%d (1..4)", nseg);
+  for (int i = 0; i < nseg; ++i) ALVQ_REQUIRE(dy[i] && x[i], ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3_multi: null segment %d", i);
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3_multi: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16x3_multi: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3_multi: w_layout");
+  return wgrad_x3_launch(dy, x, nseg, dw, nullptr, workspace, B, C, M, L, KW, w_layout, accumulate, (hipStream_t)stream);
 }

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "alvq_conv1d_f16mx": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p] * 4),
     "alvq_conv1d_wgrad_f16mx_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_f16mx": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p, _c_void_p]),
+    "alvq_conv1d_wgrad_bf16x3_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p]),
     "alvq_conv1d_wgrad_f16mx_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p, _c_void_p]),
     "alvq_onehot_to_index_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
     "alvq_embedding_bag_fwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 4 + [_c_void_p]),
@@ -762,11 +763,11 @@ def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=F
     """dw (+)= sum_i wgrad(dy_i, x_i) in one launch (shared residual weights).  pairs: [(dy NLC, x NLC), ...] (1..4)."""
     dy0, x0 = pairs[0]
     M, C = dy0.C, x0.C
-    fx = dy0.fmt == "f16mx"
+    fx, x3 = dy0.fmt == "f16mx", dy0.fmt == "bf16x3"
     for dy, x in pairs:
         if (dy.B, dy.L, dy.C, dy.fmt, x.B, x.L, x.C, x.fmt) != (dy0.B, dy0.L, M, dy0.fmt, x0.B, x0.L, C, dy0.fmt) or \
-                (dy.planes, x.planes) != ((2, 2) if fx else (1, 1)):
-            raise RuntimeError("conv1d_wgrad_bf16_multi: all segments must share one shape and format (plain bf16 or f16mx)")
+                (dy.planes, x.planes) != ((2, 2) if (fx or x3) else (1, 1)):
+            raise RuntimeError("conv1d_wgrad_bf16_multi: all segments must share one shape and format")
         if fx and dy.gscale is not dy0.gscale:
             raise RuntimeError("conv1d_wgrad_bf16_multi: the segments belong to different loss-scale chains")
     shape = (M, C, KW) if w_layout == W_OIK else (C, M, KW)
@@ -785,6 +786,13 @@ def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=F
             rc = lib().alvq_conv1d_wgrad_f16mx_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws.data_ptr(), x0.B, C, M, x0.L, KW,
                                                      w_layout, int(bool(accumulate)), _sptr(dy0.gscale, 1), _stream())
         _check(rc, "alvq_conv1d_wgrad_f16mx_multi")
+        return dw_out
+    if x3:
+        ws = _workspace(lib().alvq_conv1d_wgrad_bf16x3_workspace_bytes(x0.B, C, M, x0.L, KW), dev)
+        with _timed("conv1d_wgrad_bf16x3_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):
+            rc = lib().alvq_conv1d_wgrad_bf16x3_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws.data_ptr(), x0.B, C, M, x0.L, KW,
+                                                      w_layout, int(bool(accumulate)), _stream())
+        _check(rc, "alvq_conv1d_wgrad_bf16x3_multi")
         return dw_out
     ws = _workspace(lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x0.B, C, M, x0.L, KW), dev)
     with _timed("conv1d_wgrad_bf16_v2_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):

@@ -272,8 +272,8 @@ class _BF16Engine:
 
     @property
     def wgrad_multi(self):
-        """sum_i wgrad(dy_i, x_i) in one launch -- bf16 and f16mx (the split-bf16 mode loops)."""
-        return N.conv1d_wgrad_bf16_multi if self.planes == 1 else None
+        """sum_i wgrad(dy_i, x_i) in one launch (every NLC mode)."""
+        return N.conv1d_wgrad_bf16_multi
 
     def pack(self, act):
         return act.storage, (act.B, act.L, act.C, act.planes, act.has_bits, act.fmt)

@@ -270,6 +270,10 @@ int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bias, const v
 int64_t alvq_conv1d_wgrad_bf16x3_workspace_bytes(int B, int C, int M, int L, int KW);
 int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
                              int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
+/* dw (+)= sum_i wgrad(dy[i], x[i]) over nseg (1..4) pairs of one shape in ONE launch (the R uses of a shared residual
+ * weight), as alvq_conv1d_wgrad_bf16_multi. */
+int alvq_conv1d_wgrad_bf16x3_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                   int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
 
 /* ================================================================================================
  * "f16mx" split path: fp32-grade results at TWO matrix-pipe units per product.  Every value v is H = fp16(v) plus

@@ -81,6 +81,28 @@ def test_conv_bf16x3_epilogue_fusions():
     assert rel(y.to_ncl(), v) < 3e-5 and rel(y2.to_ncl(), v + post) < 3e-5
 
 
+@pytest.mark.parametrize("KW", [1, 3])
+@pytest.mark.parametrize("nseg", [2, 3, 4])
+def test_wgrad_bf16x3_multi_sums_the_uses_of_a_shared_weight(nseg, KW):
+    """One launch over nseg (dy, x) pairs == the sum of nseg single launches (residual_stack.py:40-41 shares one weight
+    between the R layers); accumulate adds to what dw held."""
+    torch.manual_seed(8)
+    B, C, M, L = 3, 72, 136, 95
+    xs = [torch.randn(B, C, L) for _ in range(nseg)]
+    dys = [torch.randn(B, M, L) for _ in range(nseg)]
+    w = (torch.randn(M, C, KW) / (C * KW) ** 0.5).requires_grad_(True)
+    for x, dy in zip(xs, dys):
+        F.conv1d(x, w, None, padding=KW // 2).backward(dy)
+    pairs = [(N.ncl_to_nlc(dy.cuda(), 2), N.ncl_to_nlc(x.cuda(), 2)) for dy, x in zip(dys, xs)]
+    dw = N.conv1d_wgrad_bf16_multi(pairs, KW, N.W_OIK)
+    assert rel(dw, w.grad) < 5e-5
+    singles = sum(N.conv1d_wgrad_bf16(dy, x, KW, N.W_OIK) for dy, x in pairs)
+    assert rel(dw, singles) < 1e-6
+    base = torch.randn(M, C, KW, device="cuda")
+    acc = N.conv1d_wgrad_bf16_multi(pairs, KW, N.W_OIK, dw_out=base.clone(), accumulate=True)
+    assert rel(acc, base.cpu() + w.grad) < 5e-5
+
+
 @pytest.mark.parametrize("B,C,M,L,KW", SHAPES)
 def test_wgrad_bf16x3_matches_fp32(B, C, M, L, KW):
     torch.manual_seed(3)
