@@ -83,6 +83,7 @@ int conv1d_bf16_v2_launch(const ConvBArgs& a, int KW, hipStream_t stream);
 int conv1d_bf16_k3_launch(const ConvBArgs& a, hipStream_t stream);
 // defined in conv1d_wgrad_bf16_v2.hip: ring-pipelined weight-gradient (+ its fixed-order split reduction)
 int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int KW);
+int conv1d_wgrad_bf16_v2_splits(int total_rows, int C, int M, int KW, int nseg, bool with_bias);
 // dbias (optional): the bias gradient, fused into the same launch; bias_partial: >= 64 * pad64(M) floats of scratch
 int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
                                 int total_rows, int C, int M, int KW, int w_layout, int accumulate, hipStream_t s,

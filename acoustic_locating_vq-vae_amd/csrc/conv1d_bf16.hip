@@ -313,6 +313,11 @@ extern "C" int64_t alvq_conv1d_wgrad_bf16_workspace_bytes(int B, int C, int M, i
   return wgrad_bias_offset((int)alvq_nlc_rows(B, L), C, M, KW) + (int64_t)64 * pad_to(M, TB_K) * 4;
 }
 
+extern "C" int alvq_conv1d_wgrad_bf16_splits(int B, int C, int M, int L, int KW, int nseg, int with_bias) {
+  if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3) || nseg < 1 || nseg > 4) return -1;
+  return conv1d_wgrad_bf16_v2_splits((int)alvq_nlc_rows(B, L), C, M, KW, nseg, with_bias != 0);
+}
+
 extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C,
                                       int M, int L, int KW, int w_layout, int accumulate, void* stream) {
   ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16: null pointer");

@@ -677,18 +677,9 @@ static constexpr int wgrad_x3_lds() {
   return 2 * (2 * 32 * 256 + 2 * (KW == 1 ? 32 : 36) * (4 * NCF * 16 * 2));
 }
 
-static int wgrad_x3_splits(int total_rows, int tiles, int* chunks_per_split) {
-  const int nchunks = total_rows / 64;
-  int want = (256 + tiles - 1) / tiles;
-  if (want < 1) want = 1;
-  if (want > nchunks) want = nchunks;
-  if (want > 64) want = 64;
-  const int cps = (nchunks + want - 1) / want;
-  *chunks_per_split = cps;
-  return (nchunks + cps - 1) / cps;
-}
+static int wgrad_x3_tiles(int C, int M, int KW) { return ((M + 127) / 128) * ((C + (KW == 3 ? 128 : 256) - 1) / (KW == 3 ? 128 : 256)); }
 
-constexpr int X3_BIAS_SPLITS = 64;     // upper bound of the split count (wgrad_x3_splits)
+constexpr int X3_BIAS_SPLITS = 64;     // upper bound of the split count (wgrad_split_plan)
 
 }  // namespace alvq
 
@@ -774,13 +765,7 @@ extern "C" int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bi
 
 extern "C" int64_t alvq_conv1d_wgrad_bf16x3_workspace_bytes(int B, int C, int M, int L, int KW) {
   if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3)) return -1;
-  const int rows = (int)alvq_nlc_rows(B, L);
-  const int ct = KW == 3 ? 128 : 256;
-  const int tiles = ((M + 127) / 128) * ((C + ct - 1) / ct);
-  int cps;
-  int splits = wgrad_x3_splits(rows, tiles, &cps);
-  const int splits_multi = wgrad_x3_splits(WX_MAXSEG * rows, tiles, &cps);   // the split count never exceeds this
-  if (splits_multi > splits) splits = splits_multi;
+  const int splits = wgrad_split_bound((int)alvq_nlc_rows(B, L), wgrad_x3_tiles(C, M, KW), WX_MAXSEG);
   return (int64_t)splits * KW * M * C * 4 + (int64_t)X3_BIAS_SPLITS * pad_to(M, 64) * 4;
 }
 
@@ -801,7 +786,9 @@ static int wgrad_x3_launch(const void* const* dy, const void* const* x, int nseg
   a.Mp = pad_to(M, 64); a.Cp = pad_to(C, 64); a.M = M; a.C = C;
   a.mtiles = (M + 127) / 128; a.ctiles = (C + ct - 1) / ct;
   a.total_rows = rows;
-  a.splits = wgrad_x3_splits(nseg * rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  a.splits = wgrad_split_plan(nseg * rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  ALVQ_REQUIRE(a.mtiles * a.ctiles == wgrad_x3_tiles(C, M, KW) && a.splits <= wgrad_split_bound(rows, wgrad_x3_tiles(C, M, KW), WX_MAXSEG),
+               ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16x3: %d splits exceed what alvq_conv1d_wgrad_bf16x3_workspace_bytes sizes", a.splits);
   float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
   if (dbias) a.bias_partial = bpart;
   static DeviceOnce attr;
@@ -819,6 +806,12 @@ static int wgrad_x3_launch(const void* const* dy, const void* const* x, int nseg
     hipLaunchKernelGGL(wgrad_x3_bias_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bpart, dbias, a.splits,
                        a.Mp, M, accumulate);
   return check_launch("alvq_conv1d_wgrad_bf16x3/reduce");
+}
+
+extern "C" int alvq_conv1d_wgrad_bf16x3_splits(int B, int C, int M, int L, int KW, int nseg) {
+  if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3) || nseg < 1 || nseg > WX_MAXSEG) return -1;
+  int cps;
+  return wgrad_split_plan(nseg * (int)alvq_nlc_rows(B, L), wgrad_x3_tiles(C, M, KW), &cps);
 }
 
 extern "C" int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C,

@@ -522,31 +522,31 @@ static constexpr int wgrad_v2_lds() {
   return 4 * (32 * 256 + (KW == 1 ? 32 : 36) * (4 * NCF * 16 * 2));
 }
 
-static int wgrad_v2_splits(int total_rows, int tiles, int* chunks_per_split) {
-  const int nchunks = total_rows / 64;
-  int want = (256 + tiles - 1) / tiles;   // one workgroup per CU
-  if (want < 1) want = 1;
-  if (want > nchunks) want = nchunks;
-  if (want > 64) want = 64;
-  const int cps = (nchunks + want - 1) / want;
-  *chunks_per_split = cps;
-  return (nchunks + cps - 1) / cps;
+// ALVQ_WGRAD_V3 (read once): which launches without a bias gradient (the shared residual weights) run the v3 kernels --
+// 0 none, 1 width 1 only, 3 (default) both.
+static int wgrad_v3_select() {
+  static const int sel = getenv("ALVQ_WGRAD_V3") ? atoi(getenv("ALVQ_WGRAD_V3")) : 3;
+  return sel;
+}
+static bool wgrad_uses_v3(int KW, bool with_bias) {
+  return !with_bias && ((KW == 1 && (wgrad_v3_select() & 1)) || (KW == 3 && (wgrad_v3_select() & 2)));
+}
+// tiles of a launch: 128 m x {128 c x 3 taps | 256 c}; the v3 width-1 kernel owns 256 m x 256 c
+static int wgrad_v2_tiles(int C, int M, int KW, bool v3) {
+  const int ct = KW == 3 ? 128 : 256, mt = (v3 && KW == 1) ? 256 : 128;
+  return ((M + mt - 1) / mt) * ((C + ct - 1) / ct);
+}
+
+int conv1d_wgrad_bf16_v2_splits(int total_rows, int C, int M, int KW, int nseg, bool with_bias) {
+  int cps;
+  return wgrad_split_plan(nseg * total_rows, wgrad_v2_tiles(C, M, KW, wgrad_uses_v3(KW, with_bias)), &cps);
 }
 
 int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int KW) {
-  const int ct = KW == 3 ? 128 : 256;
-  const int tiles = ((M + 127) / 128) * ((C + ct - 1) / ct);
-  int cps;
-  int splits = wgrad_v2_splits(WG_MAXSEG * total_rows, tiles, &cps);   // the split count never exceeds this
-  const int splits1 = wgrad_v2_splits(total_rows, tiles, &cps);
-  if (splits1 > splits) splits = splits1;
-  if (KW == 1) {     // the 256 x 256 kernel has fewer tiles, hence more splits
-    const int tiles_k1 = ((M + 255) / 256) * ((C + 255) / 256);
-    const int sk = wgrad_v2_splits(WG_MAXSEG * total_rows, tiles_k1, &cps), sk1 = wgrad_v2_splits(total_rows, tiles_k1, &cps);
-    if (sk > splits) splits = sk;
-    if (sk1 > splits) splits = sk1;
-  }
-  return (int64_t)splits * KW * M * C * 4;
+  // the larger of the two kernels' bounds: either may serve a launch of this shape (with / without a bias gradient)
+  const int s2 = wgrad_split_bound(total_rows, wgrad_v2_tiles(C, M, KW, false), WG_MAXSEG);
+  const int s3 = wgrad_split_bound(total_rows, wgrad_v2_tiles(C, M, KW, true), WG_MAXSEG);
+  return (int64_t)(s2 > s3 ? s2 : s3) * KW * M * C * 4;
 }
 
 int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
@@ -564,11 +564,12 @@ int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int
   a.Mp = Mp; a.Cp = Cp; a.M = M; a.C = C;
   a.mtiles = (M + 127) / 128; a.ctiles = (C + ct - 1) / ct;
   a.total_rows = total_rows; a.nseg = nseg;
-  // no bias gradient (the shared residual weights): the v3 kernels.  ALVQ_WGRAD_V3 = 0 none, 1 width 1 only, 3 (default) both.
-  const int v3_sel = getenv("ALVQ_WGRAD_V3") ? atoi(getenv("ALVQ_WGRAD_V3")) : 3;
-  const bool v3 = !dbias && ((KW == 1 && (v3_sel & 1)) || (KW == 3 && (v3_sel & 2)));
+  const bool v3 = wgrad_uses_v3(KW, dbias != nullptr);        // no bias gradient (the shared residual weights): the v3 kernels
   if (v3 && KW == 1) a.mtiles = (M + 255) / 256;
-  a.splits = wgrad_v2_splits(nseg * total_rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  a.splits = wgrad_split_plan(nseg * total_rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  ALVQ_REQUIRE(a.mtiles * a.ctiles == wgrad_v2_tiles(C, M, KW, v3) &&
+                   (int64_t)a.splits * KW * M * C * 4 <= conv1d_wgrad_bf16_v2_workspace_bytes(total_rows, C, M, KW),
+               ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16: %d splits exceed what alvq_conv1d_wgrad_bf16_workspace_bytes sizes", a.splits);
   static DeviceOnce attr;
   if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v3_kernel<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v3_lds<1, 2, 4>());

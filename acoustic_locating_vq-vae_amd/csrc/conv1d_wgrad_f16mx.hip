@@ -337,15 +337,10 @@ static constexpr int wgrad_fx_lds() {
   return 2 * (2 * 32 * (2 * MF * 32 * 2) + 2 * (KW == 1 ? 32 : 36) * (4 * NC * 32 * 2));
 }
 
-static int wgrad_fx_splits(int total_rows, int tiles, int* chunks_per_split) {
-  const int nchunks = total_rows / 64;
-  int want = (256 + tiles - 1) / tiles;
-  if (want < 1) want = 1;
-  if (want > nchunks) want = nchunks;
-  if (want > 64) want = 64;
-  const int cps = (nchunks + want - 1) / want;
-  *chunks_per_split = cps;
-  return (nchunks + cps - 1) / cps;
+// tiles of a launch: 128 x 128 x 3 taps for width 3, 256 x 256 for width 1
+static int wgrad_fx_tiles(int C, int M, int KW) {
+  const int ct = KW == 3 ? 128 : 256, mt = KW == 3 ? 128 : 256;
+  return ((M + mt - 1) / mt) * ((C + ct - 1) / ct);
 }
 
 }  // namespace alvq
@@ -359,14 +354,7 @@ static inline long nlc_plane_elems(int B, int L, int C) {
 
 extern "C" int64_t alvq_conv1d_wgrad_f16mx_workspace_bytes(int B, int C, int M, int L, int KW) {
   if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3)) return -1;
-  const int rows = (int)alvq_nlc_rows(B, L);
-  const int ct = KW == 3 ? 128 : 256;
-  int cps;
-  const int mt = KW == 3 ? 128 : 256;
-  const int tiles = ((M + mt - 1) / mt) * ((C + ct - 1) / ct);
-  int splits = wgrad_fx_splits(rows, tiles, &cps);
-  const int splits_multi = wgrad_fx_splits(WF_MAXSEG * rows, tiles, &cps);   // the split count never exceeds this
-  if (splits_multi > splits) splits = splits_multi;
+  const int splits = wgrad_split_bound((int)alvq_nlc_rows(B, L), wgrad_fx_tiles(C, M, KW), WF_MAXSEG);
   return (int64_t)splits * KW * M * C * 4 + (int64_t)FX_BIAS_SPLITS * pad_to(M, 64) * 4;
 }
 
@@ -389,7 +377,9 @@ static int wgrad_fx_launch(const void* const* dy, const void* const* x, int nseg
   a.total_rows = rows; a.e = FX_E_ACT;
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
   a.dbg = dbg_env;
-  a.splits = wgrad_fx_splits(nseg * rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  a.splits = wgrad_split_plan(nseg * rows, a.mtiles * a.ctiles, &a.chunks_per_split);
+  ALVQ_REQUIRE(a.mtiles * a.ctiles == wgrad_fx_tiles(C, M, KW) && a.splits <= wgrad_split_bound(rows, wgrad_fx_tiles(C, M, KW), WF_MAXSEG),
+               ALVQ_EINVAL, "alvq_conv1d_wgrad_f16mx: %d splits exceed what alvq_conv1d_wgrad_f16mx_workspace_bytes sizes", a.splits);
   float* bpart = (float*)((char*)workspace + (int64_t)a.splits * KW * M * C * 4);
   static DeviceOnce attr;
   if (attr.need()) {
@@ -415,6 +405,12 @@ static int wgrad_fx_launch(const void* const* dy, const void* const* x, int nseg
                        accumulate, inv_scale);
   }
   return check_launch("alvq_conv1d_wgrad_f16mx/reduce");
+}
+
+extern "C" int alvq_conv1d_wgrad_f16mx_splits(int B, int C, int M, int L, int KW, int nseg) {
+  if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3) || nseg < 1 || nseg > WF_MAXSEG) return -1;
+  int cps;
+  return wgrad_split_plan(nseg * (int)alvq_nlc_rows(B, L), wgrad_fx_tiles(C, M, KW), &cps);
 }
 
 extern "C" int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C, int M,

@@ -132,6 +132,30 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
   }
 }
 
+// Split plan of the NLC weight-gradient kernels (bf16, bf16x3, f16mx): the contraction runs over `total_rows` (a multiple
+// of 64; nseg * rows for a multi-segment launch) and is cut into about 256 / tiles ranges (one workgroup per CU), at most 64.
+static inline int wgrad_split_plan(int total_rows, int tiles, int* chunks_per_split) {
+  const int nchunks = total_rows / 64;
+  int want = (256 + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  if (want > nchunks) want = nchunks;
+  if (want > 64) want = 64;
+  const int cps = (nchunks + want - 1) / want;
+  *chunks_per_split = cps;
+  return (nchunks + cps - 1) / cps;
+}
+
+// Largest split count any launch over 1..maxseg segments of `rows` rows can use.  ceil(n / ceil(n / want)) is NOT monotone
+// in n (round-2 advisor finding: sizing for maxseg * rows alone under-sized the 3-segment launches), so take the maximum.
+static inline int wgrad_split_bound(int rows, int tiles, int maxseg) {
+  int best = 1, cps;
+  for (int s = 1; s <= maxseg; ++s) {
+    const int k = wgrad_split_plan(s * rows, tiles, &cps);
+    if (k > best) best = k;
+  }
+  return best;
+}
+
 static inline void wgrad_reduce_launch(const float* partial, float* dw, int splits, int KW, int M, int C, int w_layout,
                                        int accumulate, hipStream_t s) {
   if (w_layout == ALVQ_W_IOK) {

@@ -86,6 +86,9 @@ _SIGNATURES = {
     "alvq_conv1d_wgrad_f16mx": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p, _c_void_p]),
     "alvq_conv1d_wgrad_bf16x3_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p]),
     "alvq_conv1d_wgrad_f16mx_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p, _c_void_p]),
+    "alvq_conv1d_wgrad_bf16_splits": (_i32, [_i32] * 7),
+    "alvq_conv1d_wgrad_bf16x3_splits": (_i32, [_i32] * 6),
+    "alvq_conv1d_wgrad_f16mx_splits": (_i32, [_i32] * 6),
     "alvq_onehot_to_index_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
     "alvq_embedding_bag_fwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 4 + [_c_void_p]),
     "alvq_embedding_bag_bwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 5 + [_c_void_p]),

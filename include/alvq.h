@@ -250,6 +250,10 @@ int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbia
  * pointers; no bias gradient (those layers have none).  Workspace: alvq_conv1d_wgrad_bf16_workspace_bytes. */
 int alvq_conv1d_wgrad_bf16_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
                                  int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
+/* Host-only: the number of split partials (each KW*M*C floats at the start of `workspace`) a launch over nseg segments
+ * writes; never more than alvq_conv1d_wgrad_*_workspace_bytes sizes for any nseg in 1..4 (the launch re-checks it).
+ * with_bias: the single-segment launch that also produces dbias.  -1 for unsupported arguments. */
+int alvq_conv1d_wgrad_bf16_splits(int B, int C, int M, int L, int KW, int nseg, int with_bias);
 
 /* ================================================================================================
  * Split-bf16 ("bf16x3") path: fp32-grade results on the bf16 matrix cores (gfx950 has no TF32/xf32 and its
@@ -274,6 +278,7 @@ int alvq_conv1d_wgrad_bf16x3(const void* dy, const void* x, float* dw, float* db
  * weight), as alvq_conv1d_wgrad_bf16_multi. */
 int alvq_conv1d_wgrad_bf16x3_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
                                    int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream);
+int alvq_conv1d_wgrad_bf16x3_splits(int B, int C, int M, int L, int KW, int nseg);   /* as alvq_conv1d_wgrad_bf16_splits */
 
 /* ================================================================================================
  * "f16mx" split path: fp32-grade results at TWO matrix-pipe units per product.  Every value v is H = fp16(v) plus
@@ -307,6 +312,7 @@ int alvq_conv1d_wgrad_f16mx(const void* dy, const void* x, float* dw, float* dbi
 int alvq_conv1d_wgrad_f16mx_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
                                   int B, int C, int M, int L, int KW, int w_layout, int accumulate,
                                   const float* inv_scale, void* stream);
+int alvq_conv1d_wgrad_f16mx_splits(int B, int C, int M, int L, int KW, int nseg);    /* as alvq_conv1d_wgrad_bf16_splits */
 
 /* ================================================================================================
  * Location head: LocationModule.fc_1 = nn.Linear(L*K, M) on the flattened one-hot codes of a

@@ -50,3 +50,34 @@ def test_cpu_tensor_rejected(native):
     import torch
     with pytest.raises(RuntimeError, match="GPU"):
         native.conv1d(torch.zeros(1, 1, 4), torch.zeros(1, 1, 3))
+
+
+def test_wgrad_workspace_covers_every_segment_count(native):
+    """Round-2 advisor finding: ceil(n / ceil(n / want)) is not monotone in n, so a workspace sized for 1 and 4 segments
+    under-sized some 3-segment launches (e.g. f16mx, 1024 x 128 width 1, B = 5: 60 splits needed, 54 sized).  The split
+    count of every launch (nseg = 1..4, with / without the fused bias gradient) must fit what *_workspace_bytes sizes."""
+    lib = native.lib()
+    shapes = [(1024, 128, 1), (128, 1024, 1), (1024, 1024, 1), (1024, 1024, 3), (64, 1024, 3), (1024, 64, 1), (201, 1024, 3),
+              (1024, 201, 3), (16, 7, 3), (500, 1024, 3), (192, 1024, 3), (1, 1024, 3)]
+    bias_floats = {"bf16": 64, "bf16x3": 64, "f16mx": 128}
+    worst = 0
+    for C, M, KW in shapes:
+        for L in (201, 500, 13):
+            for B in list(range(1, 81)) + [96, 128, 256]:
+                per = KW * M * C * 4
+                pad_m = (M + 63) // 64 * 64
+                for fmt in ("bf16", "bf16x3", "f16mx"):
+                    ws = getattr(lib, "alvq_conv1d_wgrad_%s_workspace_bytes" % fmt)(B, C, M, L, KW)
+                    sized = (ws - bias_floats[fmt] * pad_m * 4) // per
+                    for nseg in (1, 2, 3, 4):
+                        if fmt == "bf16":
+                            used = max(lib.alvq_conv1d_wgrad_bf16_splits(B, C, M, L, KW, nseg, 0),
+                                       lib.alvq_conv1d_wgrad_bf16_splits(B, C, M, L, KW, 1, 1))
+                        else:
+                            used = getattr(lib, "alvq_conv1d_wgrad_%s_splits" % fmt)(B, C, M, L, KW, nseg)
+                        assert 1 <= used <= min(sized, 64), (fmt, B, C, M, L, KW, nseg, used, sized)
+                        worst = max(worst, used)
+    assert worst == 64                                       # the sweep reaches the cap
+    assert lib.alvq_conv1d_wgrad_f16mx_splits(5, 128, 1024, 500, 1, 3) == 60   # the advisor's case: needs 60 ...
+    assert lib.alvq_conv1d_wgrad_f16mx_workspace_bytes(5, 128, 1024, 500, 1) >= 60 * 1024 * 128 * 4   # ... and gets them
+    assert lib.alvq_conv1d_wgrad_f16mx_splits(5, 128, 1024, 500, 1, 5) == -1
