@@ -1,7 +1,10 @@
 """Build libalvq.so (the C-ABI HIP library) in-tree for gfx950.
 
-    python build.py            # incremental
+    python build.py                    # incremental
     python build.py --force
+    python build.py --debug-kernels    # lib/libalvq_dbg.so: also the timing-ablation / phase-stamp instantiations of the
+                                       # f16mx kernels (ALVQ_FX_DBG; tools/ablate_f16mx.sh loads it through ALVQ_LIB).
+                                       # The shipped libalvq.so never contains them.
 
 hipcc cross-compiles without a GPU.  Output: <this dir>/lib/libalvq.so (git-ignored, but it
 travels to the GPU box with the gpurun snapshot).
@@ -31,19 +34,22 @@ def _stamp(path):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, debug_kernels=False):
+    global OBJ
     os.makedirs(OUT, exist_ok=True)
-    os.makedirs(OBJ, exist_ok=True)
-    lib = os.path.join(OUT, "libalvq.so")
-    stamp_file = os.path.join(OBJ, "stamp")
-    stamp = _stamp(CSRC)
+    flags = FLAGS + (["-DALVQ_DEBUG_KERNELS"] if debug_kernels else [])
+    obj_dir = OBJ + ("_dbg" if debug_kernels else "")
+    os.makedirs(obj_dir, exist_ok=True)
+    lib = os.path.join(OUT, "libalvq_dbg.so" if debug_kernels else "libalvq.so")
+    stamp_file = os.path.join(obj_dir, "stamp")
+    stamp = _stamp(CSRC) + ("dbg" if debug_kernels else "")
     if not force and os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return lib
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
     def cc(src):
-        obj = os.path.join(OBJ, src[:-4] + ".o")
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(obj_dir, src[:-4] + ".o")
+        cmd = [HIPCC] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -61,4 +67,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, debug_kernels="--debug-kernels" in sys.argv))

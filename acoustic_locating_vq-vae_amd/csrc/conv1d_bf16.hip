@@ -210,7 +210,6 @@ __global__ __launch_bounds__(256) void relu_mask_bf16_kernel(const u16* dy, cons
 using namespace alvq;
 
 static inline int pad_to(int x, int q) { return (x + q - 1) / q * q; }
-constexpr long ALVQ_WIDE_MIN_TILES = 192;   // 256 x 256-tile kernels need about one workgroup per CU to pay off
 
 extern "C" int64_t alvq_nlc_rows(int B, int L) { return (B <= 0 || L <= 0) ? -1 : (int64_t)pad_to(1 + B * (L + 1), NLC_ROW_PAD); }
 extern "C" int alvq_nlc_channels(int C) { return C <= 0 ? -1 : pad_to(C, TB_K); }
@@ -277,14 +276,12 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
   // activation slab, or the generic one; narrow or ragged M (128, 192, 201, 64, 1) stays on 128 x 128 tiles, which
   // waste less there and give more workgroups.  ALVQ_CONV_V2=0 / ALVQ_CONV_K3=0 force the fallbacks (used by
   // tools/ab_kernels.py to cross-check and compare the kernels on one device).
-  static int use_v2 = -1, use_k3 = -1;
-  if (use_v2 < 0) use_v2 = getenv("ALVQ_CONV_V2") ? atoi(getenv("ALVQ_CONV_V2")) : 1;
-  if (use_k3 < 0) use_k3 = getenv("ALVQ_CONV_K3") ? atoi(getenv("ALVQ_CONV_K3")) : 1;
+  const long use_v2 = option(OPT_CONV_V2), use_k3 = option(OPT_CONV_K3);
   // ... and only when that gives every CU a workgroup: a small problem (the RIR config: 26 row tiles x 4 m-tiles = 104
-  // workgroups of 256 x 256 for 256 CUs) is better served by four times as many 128 x 128 tiles at two per CU
+  // workgroups of 256 x 256 for 256 CUs) is better served by four times as many 128 x 128 tiles at two per CU.
+  // Option "wide_min_tiles" (default 192; the unit tests lower it to drive the wide kernels with small problems).
   const long tiles256 = (alvq_nlc_rows(B, L) / 256) * (pad_to(M, 256) / 256);
-  static long min_tiles = -1;      // ALVQ_WIDE_MIN_TILES=1 lets the unit tests drive the wide kernels with small problems
-  if (min_tiles < 0) min_tiles = getenv("ALVQ_WIDE_MIN_TILES") ? atol(getenv("ALVQ_WIDE_MIN_TILES")) : ALVQ_WIDE_MIN_TILES;
+  const long min_tiles = option(OPT_WIDE_MIN_TILES);
   if (use_v2 && pad_to(M, 256) - M <= 32 && tiles256 >= min_tiles)
     return (KW == 3 && use_k3) ? conv1d_bf16_k3_launch(a, s) : conv1d_bf16_v2_launch(a, KW, s);
   static DeviceOnce attr;

@@ -707,7 +707,11 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
                 (const unsigned char*)mask_bits, (unsigned char*)relu_bits_out},
                nlc_plane_elems(B, L, C), (long)alvq_packed_weight_elems(M, C, KW), nlc_plane_elems(B, L, M),
                FX_E_W, FX_E_ACT, out_scale, nullptr, 0};
+#ifdef ALVQ_DEBUG_KERNELS   // the ablation / phase-stamp instantiations exist only in the debug library (build.py --debug-kernels)
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
+#else
+  constexpr int dbg_env = 0;
+#endif
   a.dbg = dbg_env;
   hipStream_t s = (hipStream_t)stream;
   static DeviceOnce attr;
@@ -722,21 +726,23 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 3, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<1, 1, 0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+#ifdef ALVQ_DEBUG_KERNELS
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_f16mx_kernel<0, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_LDS);
+#endif
   }
   // fewer than ~3/4 of the CUs covered by 256-row tiles (one m-tile: M <= 256; short batches): 128-row tiles
-  // (ALVQ_FX_ROWS=128|256 forces one of the two -- the tests run every shape through both)
-  const char* force = getenv("ALVQ_FX_ROWS");
-  const int forced = force ? atoi(force) : 0;
+  // (option "fx_rows" = 128 | 256 forces one of the two -- the tests run every shape through both)
+  const int forced = (int)option(OPT_FX_ROWS);
   // fp32-NCL output of at most 128 channels (the pre-VQ convolution and the data gradient that leaves the decoder): a
-  // 128-channel m-tile on 128-row tiles -- no MFMA spent on padding channels (ALVQ_FX_NARROW=0 switches it off)
-  const bool narrow = !dbg_env && y_ncl && M <= 128 && !(getenv("ALVQ_FX_NARROW") && atoi(getenv("ALVQ_FX_NARROW")) == 0);
+  // 128-channel m-tile on 128-row tiles -- no MFMA spent on padding channels (option "fx_narrow" = 0 switches it off)
+  const bool narrow = !dbg_env && y_ncl && M <= 128 && option(OPT_FX_NARROW) != 0;
   const bool half = narrow || (!dbg_env && (forced == 128 || (forced != 256 && a.b.rtiles * a.b.mtiles < 192)));
   if (half) a.b.rtiles = (int)(rows / 128);
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
+#ifdef ALVQ_DEBUG_KERNELS
   if (dbg_env && y) {
     static unsigned long long* stamps = nullptr;
     if ((dbg_env & (256 | 512)) && !stamps) (void)hipMalloc(&stamps, 4096 * 4 * sizeof(unsigned long long));
@@ -766,6 +772,7 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
     }
     return check_launch("alvq_conv1d_f16mx(dbg)");
   }
+#endif
   if (narrow) {
     if (KW == 3) hipLaunchKernelGGL((conv1d_f16mx_kernel<1, 3, 0, 1, 2>), grid, block, FX_LDS, s, a);
     else hipLaunchKernelGGL((conv1d_f16mx_kernel<1, 1, 0, 1, 2>), grid, block, FX_LDS, s, a);

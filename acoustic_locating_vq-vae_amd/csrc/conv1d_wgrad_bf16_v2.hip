@@ -522,12 +522,9 @@ static constexpr int wgrad_v2_lds() {
   return 4 * (32 * 256 + (KW == 1 ? 32 : 36) * (4 * NCF * 16 * 2));
 }
 
-// ALVQ_WGRAD_V3 (read once): which launches without a bias gradient (the shared residual weights) run the v3 kernels --
+// option "wgrad_v3": which launches without a bias gradient (the shared residual weights) run the v3 kernels --
 // 0 none, 1 width 1 only, 3 (default) both.
-static int wgrad_v3_select() {
-  static const int sel = getenv("ALVQ_WGRAD_V3") ? atoi(getenv("ALVQ_WGRAD_V3")) : 3;
-  return sel;
-}
+static int wgrad_v3_select() { return (int)option(OPT_WGRAD_V3); }
 static bool wgrad_uses_v3(int KW, bool with_bias) {
   return !with_bias && ((KW == 1 && (wgrad_v3_select() & 1)) || (KW == 3 && (wgrad_v3_select() & 2)));
 }

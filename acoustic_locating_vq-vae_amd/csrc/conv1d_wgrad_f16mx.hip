@@ -375,7 +375,11 @@ static int wgrad_fx_launch(const void* const* dy, const void* const* x, int nseg
   a.Mp = pad_to(M, 64); a.Cp = pad_to(C, 64); a.M = M; a.C = C;
   a.mtiles = (M + mt - 1) / mt; a.ctiles = (C + ct - 1) / ct;
   a.total_rows = rows; a.e = FX_E_ACT;
+#ifdef ALVQ_DEBUG_KERNELS   // ablation instantiations: debug library only (build.py --debug-kernels)
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
+#else
+  constexpr int dbg_env = 0;
+#endif
   a.dbg = dbg_env;
   a.splits = wgrad_split_plan(nseg * rows, a.mtiles * a.ctiles, &a.chunks_per_split);
   ALVQ_REQUIRE(a.mtiles * a.ctiles == wgrad_fx_tiles(C, M, KW) && a.splits <= wgrad_split_bound(rows, wgrad_fx_tiles(C, M, KW), WF_MAXSEG),
@@ -385,14 +389,19 @@ static int wgrad_fx_launch(const void* const* dy, const void* const* x, int nseg
   if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<3, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<3, 1, 2>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<1, 2, 4>());
+#ifdef ALVQ_DEBUG_KERNELS
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<3, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<3, 1, 2>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_f16mx_kernel<1, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_fx_lds<1, 2, 4>());
+#endif
   }
   const int grid = a.mtiles * a.ctiles * a.splits;
+#ifdef ALVQ_DEBUG_KERNELS
   if (dbg_env) {
     if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1, 2, true>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1, 2>()), s, a);
     else hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<1, 2, 4, true>), dim3(grid), dim3(512), (wgrad_fx_lds<1, 2, 4>()), s, a);
-  } else if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1, 2>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1, 2>()), s, a);
+  } else
+#endif
+  if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<3, 1, 2>), dim3(grid), dim3(512), (wgrad_fx_lds<3, 1, 2>()), s, a);
   else hipLaunchKernelGGL((conv1d_wgrad_f16mx_kernel<1, 2, 4>), dim3(grid), dim3(512), (wgrad_fx_lds<1, 2, 4>()), s, a);
   int rc = check_launch("alvq_conv1d_wgrad_f16mx");
   if (rc) return rc;

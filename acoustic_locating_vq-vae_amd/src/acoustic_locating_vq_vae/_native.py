@@ -29,6 +29,8 @@ _f32 = ctypes.c_float
 _SIGNATURES = {
     "alvq_version": (ctypes.c_char_p, []),
     "alvq_last_error": (ctypes.c_char_p, []),
+    "alvq_set_option": (_i32, [ctypes.c_char_p, _i64]),
+    "alvq_get_option": (_i64, [ctypes.c_char_p]),
     "alvq_conv1d_f32": (_i32, [_c_void_p] * 9 + [_i32] * 7 + [_c_void_p]),
     "alvq_conv1d_wgrad_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_f32": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
@@ -121,6 +123,20 @@ def lib():
 
 def version():
     return lib().alvq_version().decode()
+
+
+def set_option(name, value):
+    """Dispatch option of the library (include/alvq.h: alvq_set_option); returns the previous value."""
+    prev = get_option(name)
+    _check(lib().alvq_set_option(name.encode(), int(value)), "alvq_set_option")
+    return prev
+
+
+def get_option(name):
+    v = lib().alvq_get_option(name.encode())
+    if v == -(1 << 63):
+        raise KeyError(name)
+    return v
 
 
 def _check(rc, name):
@@ -701,7 +717,7 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
         family, fn = "conv1d_bf16x3_kernel", lib().alvq_conv1d_bf16x3
     else:
         # mirrors the dispatch in csrc/conv1d_bf16.hip: wide layers go to the 256x256-tile kernels (k3 for width 3)
-        min_tiles = int(os.environ.get("ALVQ_WIDE_MIN_TILES", "192"))
+        min_tiles = get_option("wide_min_tiles")
         wide = ((M + 255) // 256 * 256 - M) <= 32 and (x.rows // 256) * ((M + 255) // 256) >= min_tiles
         family = ("conv1d_bf16_k3_kernel" if KW == 3 else "conv1d_bf16_v2_kernel") if wide else "conv1d_bf16_kernel"
         fn = lib().alvq_conv1d_bf16

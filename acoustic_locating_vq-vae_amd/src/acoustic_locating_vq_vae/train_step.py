@@ -73,13 +73,14 @@ class FlatBuffers:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)
 
-    def sync_grads(self, group=None):
+    def sync_grads(self, group=None, force=False):
         """All-reduce(sum) of the whole flat gradient buffer, in place, as ONE collective.
-        Returns the factor the optimiser must apply (1/world)."""
+        Returns the factor the optimiser must apply (1/world).  A one-rank group skips the call (the sum over one rank
+        is the buffer itself) unless ``force`` -- the switch that lets a single-GPU box execute the RCCL path."""
         if not (dist.is_available() and dist.is_initialized()):
             return 1.0
         world = dist.get_world_size(group)
-        if world == 1:
+        if world == 1 and not force:
             return 1.0
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / world
@@ -94,10 +95,10 @@ class FlatBuffers:
         hi = self.offsets[last + 1] if last + 1 < len(self.offsets) else self.grad.numel()
         return self.offsets[idx[0]], hi
 
-    def sync_span(self, lo, hi, group=None):
+    def sync_span(self, lo, hi, group=None, force=False):
         """Asynchronous all-reduce(sum) of grad[lo:hi); returns the work handle (None without a process group).  The
         caller ``wait()``s it -- a stream-level wait on the GPU -- before the optimiser reads the buffer."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
             return None
         return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
 
@@ -164,8 +165,13 @@ class Trainer:
     kind="echoed":  x = standardise(echoed); x_rir = x^T; loss = mse(recon, x)                (train_echoed_speech.py)
     """
 
-    def __init__(self, model, kind="speech", lr=1e-3, group=None, grad_buckets=None):
+    def __init__(self, model, kind="speech", lr=1e-3, group=None, grad_buckets=None, force_collective=None):
+        """``force_collective`` (or ALVQ_FORCE_COLLECTIVE=1): issue the step's all-reduce even in a one-rank process
+        group, where it is the identity -- so that the RCCL call between the backward and the Adam launch can be
+        executed (and is tested, tests/test_rccl_gpu.py) on a single-GPU box."""
         self.model, self.kind, self.group = model, kind, group
+        self.force_collective = (os.environ.get("ALVQ_FORCE_COLLECTIVE", "0") != "0") if force_collective is None \
+            else bool(force_collective)
         # echoed loop: the reference hands Adam every parameter (train_echoed_speech.py:48) but detaches both encoder
         # outputs unless set_train_encoder(True) was called (echoed_speech_model.py:51-54), so only the decoder's
         # tensors ever receive gradients -- the flat buffers (and the all-reduce) hold exactly the tensors that do.
@@ -270,13 +276,13 @@ class Trainer:
             z.backward(leaf.grad)
 
     def _sync_early(self):
-        return self.buffers.sync_span(*self._buckets[0], group=self.group) if self._buckets else None
+        return self.buffers.sync_span(*self._buckets[0], group=self.group, force=self.force_collective) if self._buckets else None
 
     def _finish(self, early_work=None):
         if self._buckets is None:
-            self.buffers.sync_grads(self.group)                # single bucket: the step's one collective
+            self.buffers.sync_grads(self.group, force=self.force_collective)   # single bucket: the step's one collective
         else:
-            late_work = self.buffers.sync_span(*self._buckets[1], group=self.group)
+            late_work = self.buffers.sync_span(*self._buckets[1], group=self.group, force=self.force_collective)
             for w in (early_work, late_work):
                 if w is not None:
                     w.wait()                                   # stream-level wait: the Adam launch queues behind both

@@ -10,9 +10,12 @@ the flat gradient buffer] -> Adam, on a synthetic (B,201,500) batch already resi
 scripts/train_speech.py:152-153, B=64 per GPU, weak scaling).  Prints ONE JSON line on rank 0.
 
 What the line holds (N=1):
-  value / roofline ........ the headline mode (--dtype, default bf16 = what configs[1] literally names), hipGraph replay;
+  value / roofline ........ the headline mode (--dtype, default f16mx = the fastest mode that HOLDS the north star's parity:
+                            codebook indices bit-exact, outputs within 1e-3 of the fp32 reference), hipGraph replay;
                             `roofline` is KERNEL-ONLY (the dominant conv kernel, live HIP events over an instrumented
                             eager pass); `step_frac_of_peak` is the whole step's model FLOPs against the same peak
+  bf16_throughput_mode .... plain bf16 storage + MFMA (what configs[1] literally names): faster, but ~1 % of the codebook
+                            indices differ from the reference -- reported with that measured agreement, never as `value`
   parity .................. per mode: codebook-index agreement and z / recon / loss errors MEASURED IN THIS RUN on the
                             default-config golden made by the real reference (tests/golden/g3_speech.npz)
   north_star .............. the mode that carries the parity claim (bit-exact indices, 1e-3 forward): its throughput,
@@ -107,9 +110,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU")
     ap.add_argument("--config", default="speech", choices=["speech", "rir", "echoed"],
                     help="speech = BASELINE configs[1] (the headline); rir = configs[2]; echoed = configs[4]")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3", "f16mx"],
-                    help="bf16: BASELINE configs[1] (bf16 storage/MFMA, fp32 accumulate+master weights); f32: parity mode "
-                         "on the exact-fp32 MFMA; bf16x3: split-bf16 parity mode (3 bf16 MFMAs per product)")
+    ap.add_argument("--dtype", default="f16mx", choices=["bf16", "f32", "bf16x3", "f16mx"],
+                    help="f16mx (default): the fastest mode that holds the north star's parity (fp16 + block-scaled fp8 MFMA "
+                         "per product); bf16x3: split-bf16 parity mode (3 bf16 MFMAs per product); f32: exact-fp32 MFMA; "
+                         "bf16: throughput mode (bf16 storage/MFMA; ~1 %% of the codebook indices differ)")
     ap.add_argument("--no-secondary", "--no-f32-line", dest="no_secondary", action="store_true",
                     help="only the headline line (skip parity modes, script loop, VQ stress, rir / echoed configs)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -188,14 +192,16 @@ def main():
         fam = max((f for f in CONV_FAMILIES[dtype] if f in summ), key=lambda f: summ[f][1])
         n, secs, flops = summ[fam]
         ach = flops / secs / 1e12
-        traffic = None
+        traffic, source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(fam)
+            tj = json.load(open(tpath))
+            traffic = tj.get(fam)
+            source = "NOT measured in this run: profiles/traffic.json (%s)" % tj.get("_source", "rocprofv3 --pmc passes, tools/profile_bench.sh")
         return {"bound": "mfma", "scope": "kernel-only (dominant conv kernel, not the whole step)", "kernel": fam,
                 "achieved": ach, "peak": PEAK[dtype], "peak_is": PEAK_NOTE[dtype], "unit": "TFLOP/s",
-                "frac": ach / PEAK[dtype], "traffic": traffic, "launches": n, "avg_launch_ms": 1e3 * secs / n,
-                "algorithmic_gflop_per_launch": flops / n / 1e9}
+                "frac": ach / PEAK[dtype], "traffic": traffic, "traffic_source": source, "launches": n,
+                "avg_launch_ms": 1e3 * secs / n, "algorithmic_gflop_per_launch": flops / n / 1e9}
 
     def families(summ, steps):
         return {k: {"launches": v[0], "ms_per_step": 1e3 * v[1] / steps, "tflops": (v[2] / v[1] / 1e12) if v[1] > 0 else None}
@@ -238,6 +244,11 @@ def main():
         if summ is not None:
             res["roofline"] = roofline(summ, dtype)
             res["kernel_families"] = families(summ, summ_steps)
+            # everything that is not a convolution / weight-gradient / VQ-argmin launch (layout conversions, split
+            # reductions, quantiser epilogues, weight packing, losses, Adam): the replayed step minus the timed families
+            timed = sum(v["ms_per_step"] for v in res["kernel_families"].values())
+            res["other_kernels_ms_per_step"] = res["ms_per_step"] - timed
+            res["other_kernels_share"] = (res["ms_per_step"] - timed) / res["ms_per_step"]
         del trainer, model
         torch.cuda.empty_cache()
         return res, cfg, gf
@@ -248,8 +259,9 @@ def main():
         import g3_cases
         _ops.set_compute_dtype(mode)
         r = g3_cases.run("speech")
-        keep = ("idx_total", "idx_mismatches", "idx_agree", "mismatch_gap_max", "z_rel_max", "z_rel_l2", "recon_rel_max",
-                "recon_rel_l2", "vq_loss_rel", "recon_error_rel", "grad_rel_max", "grad_rel_l2_median")
+        keep = ("idx_total", "idx_mismatches", "idx_agree", "mismatch_gap_max", "slice_elems", "z_rel_max", "z_rel_l2", "z_sum_rel",
+                "recon_rel_max", "recon_rel_l2", "recon_sum_rel", "vq_loss_rel", "recon_error_rel", "grad_rel_max",
+                "grad_rel_l2_median", "grad_sum_rel_max", "encoder_grad_rel_max")
         out = {k: r[k] for k in keep}
         out["golden"] = "tests/golden/g3_speech.npz (speech ctor, B=2, made by the reference)"
         return out
@@ -292,7 +304,7 @@ def main():
 
     if kind == "speech" and secondary:
         modes = {}
-        for mode in ("f16mx", "bf16x3", "f32"):
+        for mode in ("f16mx", "bf16x3", "f32", "bf16"):
             if mode == args.dtype:
                 modes[mode] = head
                 continue
@@ -300,15 +312,21 @@ def main():
             modes[mode], _, _ = run_config("speech", mode, B, steps2, 2, graph=not args.no_graph,
                                            timer=not args.no_kernel_timer)
         if rank == 0:
-            for mode, key in (("f32", "f32_parity_mode"), ("bf16x3", "bf16x3_parity_mode"), ("f16mx", "f16mx_parity_mode")):
+            for mode, key in (("f32", "f32_parity_mode"), ("bf16x3", "bf16x3_parity_mode"), ("f16mx", "f16mx_parity_mode"),
+                              ("bf16", "bf16_throughput_mode")):
                 if mode != args.dtype:
                     line[key] = {k: v for k, v in modes[mode].items() if k != "kernel_families"}
             ns_mode = max(PARITY_MODES, key=lambda m: modes[m]["value"])
             line["_ns_src"] = (ns_mode, modes[ns_mode])
 
     if rank == 0 and world == 1 and kind == "speech" and not args.no_parity:
-        line["parity"] = {m: parity(m) for m in (["bf16", "f16mx", "bf16x3", "f32"] if secondary else [args.dtype])}
+        line["parity"] = {m: parity(m) for m in (["f16mx", "bf16x3", "f32", "bf16"] if secondary else [args.dtype])}
         _ops.set_compute_dtype(args.dtype)
+        if "bf16_throughput_mode" in line and "bf16" in line["parity"]:
+            b = line["parity"]["bf16"]
+            line["bf16_throughput_mode"]["parity_note"] = (
+                "NOT the north-star operating point: %d of %d codebook indices differ from the reference golden, recon "
+                "rel-L2 %.2g" % (b["idx_mismatches"], b["idx_total"], b["recon_rel_l2"]))
 
     if rank == 0 and world == 1 and kind == "speech" and secondary:
         # what scripts/train_speech.py itself gets when its imports resolve to this build: the script's own loop body
@@ -375,10 +393,10 @@ def main():
                                      % (cfgname, 2 if cfgname == "rir" else 4, args.dtype),
                          "value": r["value"], "unit": "spectrograms/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                          "launch": r["launch"], "model_tflops": r["model_tflops"], "algorithmic_gflop_per_spectrogram": gf2}
-            if args.dtype != PARITY_MODES[0]:      # the same config in the mode that carries the parity claim
-                r2, _, _ = run_config(cfgname, PARITY_MODES[0], 32, max(5, min(20, args.steps)), 3, graph=not args.no_graph, timer=False)
-                line[key]["parity_mode"] = {"dtype": PARITY_MODES[0], "value": r2["value"], "ms_per_step": r2["ms_per_step"],
-                                            "model_tflops": r2["model_tflops"]}
+            other = "bf16" if args.dtype == PARITY_MODES[0] else PARITY_MODES[0]   # the same config in the other operating point
+            r2, _, _ = run_config(cfgname, other, 32, max(5, min(20, args.steps)), 3, graph=not args.no_graph, timer=False)
+            line[key]["throughput_mode" if other == "bf16" else "parity_mode"] = {
+                "dtype": other, "value": r2["value"], "ms_per_step": r2["ms_per_step"], "model_tflops": r2["model_tflops"]}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -43,6 +43,19 @@ extern "C" {
 const char* alvq_version(void);
 const char* alvq_last_error(void);
 
+/* Dispatch options: which kernel variant serves a launch (never what it computes).  Each starts from the environment
+ * variable ALVQ_<NAME> (read once, at the first use of the library) or its default, and can be changed at run time here;
+ * the launch path reads an atomic, never the environment.  Names / defaults:
+ *   wide_min_tiles 192   bf16: 256 x 256-tile conv kernels only for problems with at least this many such tiles
+ *   conv_v2 1, conv_k3 1 bf16: the 256 x 256 kernels at all / the shared-slab width-3 form
+ *   wgrad_v3 3           bf16 weight gradient without bias: v3 kernels for width 1 (bit 0) / width 3 (bit 1)
+ *   fx_rows 0            f16mx conv row tile: 0 automatic, 128 or 256 forced
+ *   fx_narrow 1          f16mx: 128-channel m-tile for fp32-NCL outputs of <= 128 channels
+ *   fx_k1_variant 1      f16mx width-1 conv: 0 the round-2 kernel, 1 the current one
+ * alvq_set_option returns ALVQ_EINVAL for an unknown name; alvq_get_option returns INT64_MIN. */
+int alvq_set_option(const char* name, int64_t value);
+int64_t alvq_get_option(const char* name);
+
 /* ------------------------------------------------------------------------------------------------
  * 1-D convolution, stride 1, "same" padding, KW in {1,3}:  im2col-free implicit GEMM on MFMA.
  *

@@ -19,7 +19,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # The library sends a wide layer to its 256 x 256-tile kernels only when the problem has about one tile per CU (192);
 # smaller problems take the 128 x 128 kernel.  The unit tests compare against CPU references at sizes that finish in
 # seconds, so they lower that threshold to keep driving the wide kernels (k3 / v2) with small problems; the full-size
-# tests, smoke() and bench.py run the same kernels through the default dispatch.  Read once, at the first launch.
+# tests, smoke() and bench.py run the same kernels through the default dispatch, and
+# tests/test_default_configs_modes_gpu.py::test_bf16_production_dispatch runs the goldens under BOTH settings (the
+# option is re-settable at run time: alvq_set_option("wide_min_tiles", ...)).  This is the option's initial value.
 os.environ.setdefault("ALVQ_WIDE_MIN_TILES", "1")
 
 

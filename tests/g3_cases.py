@@ -42,6 +42,20 @@ def sl(t, n=64):
     return f[::step][:n].cpu().numpy()
 
 
+def wide(t, ref):
+    """The strided slice of ``t`` that matches the golden array ``ref`` (64 elements in round 1-2, thousands since round 3)."""
+    return sl(t, int(np.asarray(ref).size))
+
+
+def sum_rel(t, ref_sum):
+    """Full-tensor checksums against the golden's fp64 (sum, sum|.|, sum .^2): the three relative errors' maximum, the
+    plain sum being judged against sum|.| (it cancels)."""
+    f = t.detach().double().flatten()
+    got = (float(f.sum()), float(f.abs().sum()), float((f * f).sum()))
+    s, a, q = (float(v) for v in ref_sum)
+    return max(abs(got[0] - s) / (a + 1e-300), abs(got[1] - a) / (a + 1e-300), abs(got[2] - q) / (q + 1e-300))
+
+
 def _expand(p, R):
     out = {}
     for k, v in p.items():
@@ -61,14 +75,18 @@ def _build(cfg, p, **kw):
 
 
 def _grad_report(named_params, g, prefix=""):
-    worst, key_w, l2s = 0.0, None, []
+    worst, key_w, l2s, sums, enc_worst = 0.0, None, [], 0.0, 0.0
     for key, pp in named_params:
-        want = g["grad_slice:" + prefix + key]
-        r = rel_max(sl(pp.grad), want)
-        l2s.append(rel_l2(sl(pp.grad), want))
+        want = g["grad_wide:" + prefix + key]
+        r = rel_max(wide(pp.grad, want), want)
+        l2s.append(rel_l2(wide(pp.grad, want), want))
+        sums = max(sums, sum_rel(pp.grad, g["grad_sum:" + prefix + key]))
         if r > worst:
             worst, key_w = r, prefix + key
-    return {"grad_rel_max": worst, "grad_rel_max_key": key_w, "grad_rel_l2_median": float(np.median(l2s))}
+        if key.startswith(("_encoder", "_pre_vq_conv")):
+            enc_worst = max(enc_worst, r)
+    return {"grad_rel_max": worst, "grad_rel_max_key": key_w, "grad_rel_l2_median": float(np.median(l2s)),
+            "grad_rel_l2_max": float(np.max(l2s)), "grad_sum_rel_max": sums, "encoder_grad_rel_max": enc_worst}
 
 
 def run_vqvae(tag, golden_dir=GOLDEN):
@@ -91,7 +109,8 @@ def run_vqvae(tag, golden_dir=GOLDEN):
         target = O.standardise(tr).unsqueeze(1)
     xg = x.cuda()
     z = m._latent(xg)
-    out = {"tag": tag, "z_rel_max": rel_max(sl(z), g["z_slice"]), "z_rel_l2": rel_l2(sl(z), g["z_slice"])}
+    out = {"tag": tag, "z_rel_max": rel_max(wide(z, g["z_wide"]), g["z_wide"]), "z_rel_l2": rel_l2(wide(z, g["z_wide"]), g["z_wide"]),
+           "z_sum_rel": sum_rel(z, g["z_sum"]), "slice_elems": int(g["z_wide"].size)}
     _, _, _, idx = m.get_latent_indices(xg)
     idx = idx.cpu().numpy().astype(np.int16)
     bad = np.nonzero(idx != g["idx"])[0]
@@ -104,7 +123,8 @@ def run_vqvae(tag, golden_dir=GOLDEN):
     (err + vq_loss).backward()
     out.update(vq_loss_rel=rel_max(vq_loss, g["vq_loss"]), recon_error_rel=rel_max(err, g["recon_error"]),
                perplexity_rel=rel_max(perp, g["perplexity"]),
-               recon_rel_max=rel_max(sl(recon), g["recon_slice"]), recon_rel_l2=rel_l2(sl(recon), g["recon_slice"]))
+               recon_rel_max=rel_max(wide(recon, g["recon_wide"]), g["recon_wide"]),
+               recon_rel_l2=rel_l2(wide(recon, g["recon_wide"]), g["recon_wide"]), recon_sum_rel=sum_rel(recon, g["recon_sum"]))
     out.update(_grad_report(list(m.named_parameters()), g))
     return out
 
@@ -131,7 +151,8 @@ def run_echoed(golden_dir=GOLDEN):
     out = {"tag": "echoed", "recon_error_rel": rel_max(err, g["recon_error"]),
            "speech_perplexity_rel": rel_max(sperp, g["speech_perplexity"]),
            "rir_perplexity_rel": rel_max(rperp, g["rir_perplexity"]),
-           "recon_rel_max": rel_max(sl(recon), g["recon_slice"]), "recon_rel_l2": rel_l2(sl(recon), g["recon_slice"])}
+           "recon_rel_max": rel_max(wide(recon, g["recon_wide"]), g["recon_wide"]),
+           "recon_rel_l2": rel_l2(wide(recon, g["recon_wide"]), g["recon_wide"]), "recon_sum_rel": sum_rel(recon, g["recon_sum"])}
     out.update(_grad_report(list(model._decoder.named_parameters()), g, "_decoder."))
     out["encoders_grad_free"] = all(p.grad is None for p in model.speech_model.parameters())
     return out

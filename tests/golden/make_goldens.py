@@ -159,9 +159,13 @@ def big(tag, cfg, shape, permuted, out_channels, use_jitter, cb_scale):
            "vq_loss": vq_loss.detach().numpy(), "recon_error": recon_error.detach().numpy(),
            "perplexity": perp.detach().numpy(), "z_slice": sl(z), "z_sum": checksum(z),
            "recon_slice": sl(recon), "recon_sum": checksum(recon), "z_std": np.array(float(z.std())),
-           "cb_scale": np.array(cb_scale), "gain": np.array(GAIN)}
+           "cb_scale": np.array(cb_scale), "gain": np.array(GAIN),
+           # round 3: wide strided slices (thousands of elements) beside the 64-element ones; the *_sum checksums cover
+           # the whole tensors
+           "z_wide": sl(z, WIDE), "recon_wide": sl(recon, WIDE)}
     for key, pp in model.named_parameters():
         out["grad_slice:" + key] = sl(pp.grad)
+        out["grad_wide:" + key] = sl(pp.grad, WIDE_GRAD)
         out["grad_sum:" + key] = checksum(pp.grad)
     np.savez_compressed(os.path.join(HERE, "g3_%s.npz" % tag), **out)
     gap = (v[:, 1] - v[:, 0]) / np.abs(v[:, 0])
@@ -192,9 +196,11 @@ def g3_echoed():
     err.backward()
     out = {"recon_error": err.detach().numpy(), "speech_perplexity": sperp.detach().numpy(),
            "rir_perplexity": rperp.detach().numpy(), "recon_slice": sl(recon), "recon_sum": checksum(recon),
-           "speech_cb_scale": np.array(SPEECH_CB), "rir_cb_scale": np.array(RIR_CB), "gain": np.array(GAIN)}
+           "speech_cb_scale": np.array(SPEECH_CB), "rir_cb_scale": np.array(RIR_CB), "gain": np.array(GAIN),
+           "recon_wide": sl(recon, WIDE)}
     for key, pp in model._decoder.named_parameters():
         out["grad_slice:_decoder." + key] = sl(pp.grad)
+        out["grad_wide:_decoder." + key] = sl(pp.grad, WIDE_GRAD)
         out["grad_sum:_decoder." + key] = checksum(pp.grad)
     np.savez_compressed(os.path.join(HERE, "g3_echoed.npz"), **out)
     print("g3 echoed", float(err), float(sperp), float(rperp))
@@ -226,6 +232,8 @@ def g6_stft():
 
 
 GAIN = 0.5
+WIDE = 4096          # elements of the wide z / recon slices of the default-config goldens
+WIDE_GRAD = 2048     # ... and of each parameter gradient
 SPEECH_CB = 1.0
 RIR_CB = 1.0
 

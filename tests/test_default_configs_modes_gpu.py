@@ -1,7 +1,7 @@
 """Every compute mode at the DEFAULT configs (speech / RIR / echoed ctor sizes) against the goldens made by the real
 reference (tests/golden/g3_*.npz).  The f32 mode's strict version lives in tests/test_modules_gpu.py; here the
-throughput mode (bf16 -- what bench.py's headline runs) and the split parity mode are held to measured floors and
-ceilings, every number is printed, and no assertion is conditional on another one passing.
+throughput mode (bf16) is held to measured floors and ceilings and the split parity modes (f16mx = bench.py's headline,
+bf16x3) to the north star's bar itself; every number is printed, and no assertion is conditional on another one passing.
 
 Measured on MI355X (B=2 goldens): bf16x3  z 6e-6, recon 7e-6, 0 code mismatches, grads <= 7e-3;
                                   f16mx   z 1.3e-5 - 1.8e-5, recon 2.2e-5, 0 code mismatches, grads <= 7e-3;
@@ -42,16 +42,50 @@ def test_bf16_default_configs_against_reference_golden(mode, tag, golden_dir):
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
 @pytest.mark.parametrize("mode", ["bf16x3", "f16mx"], indirect=True)
 def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_dir):
+    """The north star's bar, unconditionally: codebook indices BIT-EXACT (0 of 1000 / 402 differ -- the goldens' smallest
+    relative top-2 gap is 3e-5, so there is no near-tie to excuse), outputs within 1e-3 (measured 2e-5) on 4096-element
+    slices AND on the fp64 checksums of the whole tensors, gradients of EVERY parameter (encoder side included) compared.
+    A regression to a single flipped code fails this test."""
     r = run(tag, golden_dir)
     print("g3-%s %s: %s" % (tag, mode, json.dumps(r)))
-    flips = 0
     if tag != "echoed":
-        flips = r["idx_mismatches"]
-        assert flips <= 1 and r["mismatch_gap_max"] < 1e-4, r      # indices bit-exact up to one reference near-tie
-        assert r["z_rel_max"] < 1e-4, r
-        assert r["vq_loss_rel"] < (1e-4 if flips == 0 else 5e-3), r
-    assert r["recon_error_rel"] < (1e-4 if flips == 0 else 5e-3), r
-    assert r["recon_rel_max"] < (1e-3 if flips == 0 else 2e-1), r   # north-star tolerance when the codes agree
-    assert r["grad_rel_max"] < (1.5e-2 if flips == 0 else 5e-2), r
+        assert r["idx_mismatches"] == 0, r
+        assert r["slice_elems"] >= 4096
+        assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-4, r
+        assert r["vq_loss_rel"] < 1e-4 and r["perplexity_rel"] < 1e-5, r
+        assert r["encoder_grad_rel_max"] < 1.5e-2, r
+    assert r["recon_error_rel"] < 1e-4, r
+    assert r["recon_rel_max"] < 1e-3 and r["recon_sum_rel"] < 1e-4, r       # north-star tolerance
+    # gradients: the ~1e-5 forward noise flips a few dozen of ~1e7 ReLU gates (pre-activations within rounding of zero);
+    # each is a full-size local error, hence a max-norm of ~5e-3 on the deepest layers while the typical tensor agrees to
+    # 3e-4 (DESIGN section 6).  Strict gradient parity (1e-3 max-norm) is the f32 mode's, tests/test_modules_gpu.py.
+    assert r["grad_rel_max"] < 1.5e-2 and r["grad_rel_l2_median"] < 1e-3 and r["grad_sum_rel_max"] < 1e-3, r
     if tag == "echoed":
         assert r["encoders_grad_free"]
+
+
+@pytest.fixture
+def wide_min_tiles(request):
+    from acoustic_locating_vq_vae import _native as N
+    prev = N.set_option("wide_min_tiles", request.param)
+    yield request.param
+    N.set_option("wide_min_tiles", prev)
+
+
+@pytest.mark.parametrize("tag", ["rir", "echoed", "speech"])
+@pytest.mark.parametrize("wide_min_tiles", [192, 1], ids=["default_dispatch", "wide_forced"], indirect=True)
+@pytest.mark.parametrize("mode", ["bf16"], indirect=True)
+def test_bf16_production_dispatch(mode, wide_min_tiles, tag, golden_dir):
+    """The bf16 dispatch a USER gets (option wide_min_tiles = 192: at the goldens' B = 2 every 1024-channel layer has
+    fewer than 192 tiles of 256 x 256 and runs the 128 x 128 kernel with its skip / mask / sign-bit epilogues) and the one
+    the rest of the test session forces (1: the 256 x 256 kernels), both against the reference goldens at the same bars.
+    Round-2 verdict: under pytest the production path of configs[2] / [4] in bf16 was never compared with a golden."""
+    from acoustic_locating_vq_vae import _native as N
+    assert N.get_option("wide_min_tiles") == wide_min_tiles
+    r = run(tag, golden_dir)
+    print("g3-%s bf16 wide_min_tiles=%d: %s" % (tag, wide_min_tiles, json.dumps(r)))
+    if tag != "echoed":
+        assert r["idx_agree"] >= 0.97 and r["mismatch_gap_max"] < 5e-3, r
+        assert r["z_rel_l2"] < 1.5e-2 and r["vq_loss_rel"] < 2e-3, r
+    assert r["recon_error_rel"] < 1e-2 and r["recon_rel_l2"] < 0.25, r
+    assert r["grad_rel_l2_median"] < 0.6, r

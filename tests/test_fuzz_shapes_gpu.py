@@ -74,13 +74,19 @@ def test_fuzz_bf16(B, C, M, L, KW, planes, tol):
         assert float(mat[:, :, M:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("rows_tile", ["128", "256"])
+@pytest.fixture
+def fx_rows(request):
+    prev = N.set_option("fx_rows", int(request.param))
+    yield request.param
+    N.set_option("fx_rows", prev)
+
+
+@pytest.mark.parametrize("fx_rows", ["128", "256"], indirect=True)
 @pytest.mark.parametrize("B,C,M,L,KW", CASES)
-def test_fuzz_f16mx(B, C, M, L, KW, rows_tile, monkeypatch):
+def test_fuzz_f16mx(B, C, M, L, KW, fx_rows):
     """The same 40 shapes through the f16mx kernels (fp16 + block-scaled fp8 MFMA per product), both row tiles of the
     convolution: ~1.5e-5 per product against the fp32 result; gap / tail rows and padded channels of both planes zero;
     the sign bits a ReLU'd output leaves behind are the signs of its H plane."""
-    monkeypatch.setenv("ALVQ_FX_ROWS", rows_tile)
     tol = 1.5e-4
     g = torch.Generator().manual_seed(B * 7919 + C * 31 + M * 17 + L * 3 + KW + 5)
     x = torch.randn(B, C, L, generator=g).requires_grad_(True)

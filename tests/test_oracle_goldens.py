@@ -154,8 +154,14 @@ def test_g3_default_configs(golden_dir, tag):
     assert rel(out["vq_loss"], g["vq_loss"]) < 1e-5
     assert rel(err, g["recon_error"]) < 1e-5
     assert rel(sl(out["recon"]), g["recon_slice"]) < 1e-4
+    # round 3: 4096-element slices and the whole-tensor checksums the GPU tests are held to
+    from g3_cases import sum_rel, wide
+    assert rel(wide(out["z"], g["z_wide"]), g["z_wide"]) < 1e-5 and sum_rel(out["z"], g["z_sum"]) < 1e-6
+    assert rel(wide(out["recon"], g["recon_wide"]), g["recon_wide"]) < 1e-4 and sum_rel(out["recon"], g["recon_sum"]) < 1e-6
     for key in p:
         assert rel(sl(p[key].grad), g["grad_slice:" + key]) < 1e-4, key
+        assert rel(wide(p[key].grad, g["grad_wide:" + key]), g["grad_wide:" + key]) < 1e-4, key
+        assert sum_rel(p[key].grad, g["grad_sum:" + key]) < 1e-5, key
 
 
 def test_g7_location_oracle_reproduces_reference(golden_dir):

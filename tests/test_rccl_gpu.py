@@ -1,0 +1,72 @@
+"""The one collective the north star specifies -- an RCCL all-reduce of the flat gradient buffer between the backward and
+the Adam launch -- executed on ROCm.  A 1-GPU box cannot hold two RCCL ranks (RCCL refuses two ranks on one device), so:
+
+* test_rccl_world1_*: a fresh child process opens a ONE-rank "nccl" group and forces the Trainer's collective
+  (Trainer(force_collective=True) / ALVQ_FORCE_COLLECTIVE=1); eager and captured steps, one span and two spans.  The
+  parameters after 3 steps must be bit-identical to the run with no collective, with exactly 1 (or 2) all_reduce calls
+  per step over exactly the flat buffer.
+* test_two_ranks_on_one_card_gloo: the N > 1 control flow of bench.py end to end, two ranks sharing the card and
+  exchanging gradients over gloo (what tools/rehearse_ranks.sh does by hand), both bucket settings, same final loss.
+
+N > 1 over RCCL stays unmeasured until the driver's 8-GPU run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _env(**extra):
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ALVQ_WIDE_MIN_TILES", None)
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("mode", ["f16mx", "bf16"])
+def test_rccl_world1_forced_collective_is_executed_and_exact(mode):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_world1.py"), mode], env=_env(RANK="0", WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RCCL_WORLD1 ")][-1]
+    r = json.loads(line[len("RCCL_WORLD1 "):])
+    print(json.dumps(r))
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["scratch_identity"]
+    for name, v in r["variants"].items():
+        want = 2 if name.endswith("buckets2") else 1
+        assert v["allreduce_calls_per_step"] == want, (name, v)
+        assert v["params_bit_identical"] and v["losses_equal"] and v["finite"], (name, v)
+        if want == 1:
+            assert v["first_call_numels"][0] == v["flat_numel"], (name, v)      # the WHOLE flat buffer in one call
+        else:
+            assert sum(v["first_call_numels"]) == v["flat_numel"], (name, v)    # two spans that partition it
+
+
+def test_two_ranks_on_one_card_gloo():
+    finals = {}
+    for buckets in ("1", "2"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+               "--batch", "8", "--no-secondary", "--no-kernel-timer", "--no-cpu-baseline", "--no-parity"]
+        p = subprocess.run(cmd, env=_env(ALVQ_BENCH_BACKEND="gloo", ALVQ_GRAD_BUCKETS=buckets), capture_output=True, text=True,
+                           timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["allreduce_calls_per_step"] == int(buckets) and line["config"]["global_batch"] == 16
+        finals[buckets] = line["final_loss"]
+    assert finals["1"] == finals["2"], finals            # same arithmetic whichever way the buffer is reduced
