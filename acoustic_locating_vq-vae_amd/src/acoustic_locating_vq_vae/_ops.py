@@ -311,8 +311,13 @@ def _engine(name=None):
     return _ENGINES[name or _DTYPE]()
 
 
+_ACT_TAP = None     # analysis hook (tools/gate_flips.py): a list that receives (engine name, saved activations) per node
+
+
 def _save(ctx, eng, tensors, acts):
     """save_for_backward(*tensors, *activation storages) + remember how to re-wrap the activations."""
+    if _ACT_TAP is not None:
+        _ACT_TAP.append((eng.name, list(acts)))
     packed = [eng.pack(a) for a in acts]
     ctx.eng_name = eng.name
     ctx.n_plain = len(tensors)

@@ -285,7 +285,7 @@ def main():
             "final_loss": head["final_loss"], "launch": head["launch"],
             "allreduce_calls_per_step": head["allreduce_calls_per_step"],
         }
-        for k in ("roofline", "kernel_families"):
+        for k in ("roofline", "kernel_families", "other_kernels_ms_per_step", "other_kernels_share"):
             if k in head:
                 line[k] = head[k]
 
