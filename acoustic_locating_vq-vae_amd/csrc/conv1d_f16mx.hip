@@ -57,9 +57,11 @@ __device__ __forceinline__ void fx_load_add16(const u16* ph, const unsigned char
   fx_join16(h0, h1, ql, s_lo, v);
 }
 
+// Store 16 consecutive channels of one row (H: 32 bytes, hi8 / lo8: 16 bytes each) and return the packed H words (the
+// sign bits of a ReLU'd output are derived from them, fx_sign_bits_of_h).
 template <bool NOSTORE = false>
-__device__ __forceinline__ void fx_store16(u16* ph, unsigned char* pq, float s_hi, float s_lo, const float (&v)[16]) {
-  unsigned h[8], qh[4], ql[4];
+__device__ __forceinline__ void fx_store16(u16* ph, unsigned char* pq, float s_hi, float s_lo, const float (&v)[16], unsigned (&h)[8]) {
+  unsigned qh[4], ql[4];
   fx_split<16>(v, s_hi, s_lo, h, qh, ql);
   if (NOSTORE) {   // timing ablation (ALVQ_FX_DBG & 512): the conversions stay, the stores go
 #pragma unroll
@@ -70,16 +72,6 @@ __device__ __forceinline__ void fx_store16(u16* ph, unsigned char* pq, float s_h
   *(u32x4*)(ph + 8) = u32x4{h[4], h[5], h[6], h[7]};
   *(u32x4*)pq = u32x4{qh[0], qh[1], qh[2], qh[3]};
   *(u32x4*)(pq + 32) = u32x4{ql[0], ql[1], ql[2], ql[3]};
-}
-
-// bit e = (the stored H of v[e] is > 0): fp16 rounds to a positive value exactly when v > 2^-25 (round to nearest even)
-__device__ __forceinline__ unsigned fx_sign_bits16(const float (&v)[16]) {
-  // as integers: bits(v) > bits(2^-25) = 0x33000000 (negative v are negative integers); the sign of the difference is
-  // the bit, shifted in from the right by v_alignbit_b32 -- two VALU instructions per element
-  unsigned bt = 0;
-#pragma unroll
-  for (int e = 15; e >= 0; --e) bt = __builtin_amdgcn_alignbit(bt, 0x33000000u - __float_as_uint(v[e]), 31);
-  return bt;
 }
 
 // Operand loads come FIRST and in bulk: one load -> use -> store chain per 32-channel tile made the epilogue a string of
@@ -170,14 +162,19 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
     }
     if (a.skip1) fx_join16(ld[ni].h0[mi], ld[ni].h1[mi], ld[ni].ql[mi], s_lo, v);
     if (a.skip2) fx_load_add16(a.skip2 + hoff, (const unsigned char*)(a.skip2 + ax.y_plane) + qoff, s_lo, v);
-    if (a.relu & 1) {
+    if (a.relu & 1) {      // one v_max_f32 per value (fmaxf costs a second one: the compiler canonicalises its operand first)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
+      for (int e = 0; e < 16; ++e) asm("v_max_f32 %0, 0, %1" : "=v"(v[e]) : "v"(v[e]));
     }
-    if (a.mask_bits) {     // sign-extend bit e to a word and AND: two VALU instructions per element
-      const int bt = (int)ld[ni].mb[mi];
+    if (a.mask_bits) {     // sign-extend bit e to a word (v_bfe_i32) and AND: two VALU instructions per element; written
+                           // as asm because the compiler turns the C form into and + compare + select with wait states
+      const unsigned bt = ld[ni].mb[mi];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (unsigned)((bt << (31 - e)) >> 31));
+      for (int e = 0; e < 16; ++e) {
+        unsigned m;
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bt), "n"(e));
+        v[e] = __uint_as_float(__float_as_uint(v[e]) & m);
+      }
     } else if (a.mask) {   // the sign of a split value is the sign of its H plane (fp16 reaches 6e-8; smaller activations are zero)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -191,16 +188,17 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;
     }
-    if (DBG && (ax.dbg & 512)) fx_store16<true>(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v);
-    else fx_store16(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v);
-    if (a.bits_out) *(unsigned short*)(a.bits_out + (hoff >> 3)) = (unsigned short)fx_sign_bits16(v);
+    unsigned hw[8];
+    if (DBG && (ax.dbg & 512)) fx_store16<true>(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v, hw);
+    else fx_store16(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v, hw);
+    if (a.bits_out) *(unsigned short*)(a.bits_out + (hoff >> 3)) = (unsigned short)fx_sign_bits_of_h(hw);
     if (a.y2) {
       fx_load_add16(a.post + hoff, (const unsigned char*)(a.post + ax.y_plane) + qoff, s_lo, v);
       if (gaps) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = ok ? v[e] : 0.f;
       }
-      fx_store16(a.y2 + hoff, (unsigned char*)(a.y2 + ax.y_plane) + qoff, s_hi, s_lo, v);
+      fx_store16(a.y2 + hoff, (unsigned char*)(a.y2 + ax.y_plane) + qoff, s_hi, s_lo, v, hw);
     }
   };
   request(0);

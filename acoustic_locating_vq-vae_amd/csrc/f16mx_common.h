@@ -59,15 +59,33 @@ __device__ __forceinline__ unsigned fx_f16_pk(float a, float b) {
 __device__ __forceinline__ float fx_h2f_lo(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[0]; }
 __device__ __forceinline__ float fx_h2f_hi(unsigned pk) { return (float)__builtin_bit_cast(f16x2_t, pk)[1]; }
 
-// four floats -> four e4m3 bytes of v / s (RNE; s a power of two), saturating at +-448 s under
-// fx_saturating_conversions() (the bare conversion returns NaN above 464).  v_cvt_scalef32_pk_fp8_f32 divides by the
-// scale inside the conversion.
+// four floats -> four e4m3 bytes of v / s (RNE; s a power of two, UNIFORM across the wave: it travels in an SGPR),
+// saturating at +-448 s under fx_saturating_conversions() (the bare conversion returns NaN above 464).
+// v_cvt_scalef32_pk_fp8_f32 divides by the scale inside the conversion and writes ONE 16-bit half of its destination,
+// so the two conversions of a word need no initialised destination (the builtin form cost a v_mov per word).
 __device__ __forceinline__ unsigned fx_fp8x4(float a, float b, float c, float d, float s) {
-  typedef short s16x2_t __attribute__((ext_vector_type(2)));
-  s16x2_t r = {0, 0};
-  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, a, b, s, false);
-  r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, s, true);
-  return __builtin_bit_cast(unsigned, r);
+  unsigned r;
+  asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(s));
+  asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(r) : "v"(c), "v"(d), "s"(s));
+  return r;
+}
+
+// v - (float)H and lo + (float)H for one half (0 = low, 1 = high) of a packed fp16 pair, each ONE v_fma_mix_f32 reading
+// the fp16 half in place (the product by +-1 is exact, so the result is the correctly rounded difference / sum, the same
+// value v_cvt_f32_f16 + v_sub / v_add produce -- the compiler does not select the mixed form by itself).
+template <int HALF>
+__device__ __forceinline__ float fx_minus_h(float v, unsigned hpk) {
+  float r;
+  if (HALF == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
+  return r;
+}
+template <int HALF>
+__device__ __forceinline__ float fx_plus_h(float lo, unsigned hpk) {
+  float r;
+  if (HALF == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(lo));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(lo));
+  return r;
 }
 
 // e4m3 byte -> float (exact); on gfx950 v_cvt_f32_fp8 with byte select
@@ -88,10 +106,8 @@ __device__ __forceinline__ void fx_split(const float (&v)[N], float s, float s_l
 #pragma unroll
   for (int e = 0; e < N / 2; ++e) {
     h[e] = fx_f16_pk(v[2 * e], v[2 * e + 1]);
-    // v - H as ONE mixed-precision FMA reading the fp16 half directly (v_fma_mix_f32; the product by -1 is exact)
-    const f16x2_t hh = __builtin_bit_cast(f16x2_t, h[e]);
-    lo[2 * e] = __builtin_fmaf((float)hh[0], -1.0f, v[2 * e]);
-    lo[2 * e + 1] = __builtin_fmaf((float)hh[1], -1.0f, v[2 * e + 1]);
+    lo[2 * e] = fx_minus_h<0>(v[2 * e], h[e]);
+    lo[2 * e + 1] = fx_minus_h<1>(v[2 * e + 1], h[e]);
   }
 #pragma unroll
   for (int e = 0; e < N / 4; ++e) {
@@ -100,13 +116,28 @@ __device__ __forceinline__ void fx_split(const float (&v)[N], float s, float s_l
   }
 }
 
-// value of 2 consecutive channels from a packed fp16 pair and the matching lo8 bytes (word, first byte index b0)
+// value of 2 consecutive channels from a packed fp16 pair and the matching lo8 bytes (word, first byte index b0 = 0 or 2):
+// lo8 * S_lo by v_cvt_scalef32_pk_f32_fp8 (two bytes per instruction; the product by a power of two is exact), then
+// + H by one v_fma_mix_f32 each -- one rounding, like the fused multiply-add it replaces
 __device__ __forceinline__ void fx_join2(unsigned hpk, unsigned qlo, int b0, float s_lo, float& v0, float& v1) {
-  // lo8 * S_lo + H: the product by a power of two is exact, so the FMA (v_fma_mix_f32 on the fp16 half) rounds once
-  // like the sum did
-  const f16x2_t hh = __builtin_bit_cast(f16x2_t, hpk);
-  v0 = __builtin_fmaf(fx_fp8_to_f(qlo, b0), s_lo, (float)hh[0]);
-  v1 = __builtin_fmaf(fx_fp8_to_f(qlo, b0 + 1), s_lo, (float)hh[1]);
+  const f32x2 lo = b0 ? __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(qlo, s_lo, true) : __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(qlo, s_lo, false);
+  v0 = fx_plus_h<0>(lo[0], hpk);
+  v1 = fx_plus_h<1>(lo[1], hpk);
+}
+
+// bit 2e / 2e+1 = (low / high fp16 half of h[e] is > 0), e = 0..7: per word max(., 0) then min(., 1) on the packed int16
+// halves (a positive fp16 is a positive int16; -0, negatives and -NaN are not), shifted into place by v_lshl_or_b32
+__device__ __forceinline__ unsigned fx_sign_bits_of_h(const unsigned (&h)[8]) {
+  const unsigned ones = 0x00010001u;
+  unsigned acc = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    unsigned t;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(t) : "v"(h[e]));
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(ones));
+    acc |= t << (2 * e);
+  }
+  return (acc & 0x5555u) | ((acc >> 15) & 0xAAAAu);
 }
 
 // byte offset of channel c (multiple of 8) inside a Q-plane row: 64 bytes per 32-channel chunk, hi8 first, lo8 at +32
