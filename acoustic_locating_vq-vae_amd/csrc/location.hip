@@ -41,12 +41,38 @@ __global__ __launch_bounds__(256) void onehot_to_index_kernel(const float* enc, 
   }
 }
 
+// (n) int64 indices -> int32, flagging any value outside [0, K) (a plain cast would wrap 2^32 + 5 to 5)
+__global__ __launch_bounds__(256) void indices_to_i32_kernel(const int64_t* idx, int32_t* out, int* flag, long n, int K) {
+  int bad = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int64_t v = idx[i];
+    const bool ok = v >= 0 && v < K;
+    out[i] = ok ? (int32_t)v : -1;
+    bad |= !ok;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// Stage the (B, L) index table in LDS; an index outside [0, K) becomes -1 (its term is skipped by both kernels: no
+// out-of-bounds read of W, no out-of-bounds += into dW) and raises the sticky device flag the caller checks, as
+// torch's embedding_bag raises on such input.
+__device__ __forceinline__ void stage_indices(const int32_t* idx, int32_t* sidx, int n, int K, int* bad_index) {
+  int bad = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int32_t v = idx[i];
+    const bool ok = v >= 0 && v < K;
+    sidx[i] = ok ? v : -1;
+    bad |= !ok;
+  }
+  if (bad_index && blockIdx.x == 0 && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(bad_index, 1);
+  __syncthreads();
+}
+
 // one wave per weight row m; the (B, L) index table is staged in LDS once per workgroup (4 rows)
 __global__ __launch_bounds__(256) void embedding_bag_fwd_kernel(const float* W, const float* bias, const int32_t* idx, float* out,
-                                                                int B, int L, int K, int M) {
+                                                                int B, int L, int K, int M, int* bad_index) {
   extern __shared__ int32_t sidx[];
-  for (int i = threadIdx.x; i < B * L; i += 256) sidx[i] = idx[i];
-  __syncthreads();
+  stage_indices(idx, sidx, B * L, K, bad_index);
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -54,7 +80,10 @@ __global__ __launch_bounds__(256) void embedding_bag_fwd_kernel(const float* W, 
   const float bm = bias ? bias[m] : 0.f;
   for (int b = 0; b < B; ++b) {
     float s = 0.f;
-    for (int l = lane; l < L; l += 64) s += w[(long)l * K + sidx[b * L + l]];
+    for (int l = lane; l < L; l += 64) {
+      const int k = sidx[b * L + l];
+      s += k >= 0 ? w[(long)l * K + k] : 0.f;
+    }
     s = wave_sum(s);
     if (lane == 0) out[(long)b * M + m] = s + bm;
   }
@@ -62,10 +91,9 @@ __global__ __launch_bounds__(256) void embedding_bag_fwd_kernel(const float* W, 
 
 // dW[m][l*K + idx[b][l]] += dz[b][m] (dW zero-filled or accumulated into by the caller's choice); lane = l, b sequential
 __global__ __launch_bounds__(256) void embedding_bag_bwd_kernel(const float* dz, const int32_t* idx, float* dW, float* dbias,
-                                                                int B, int L, int K, int M, int accumulate_bias) {
+                                                                int B, int L, int K, int M, int accumulate_bias, int* bad_index) {
   extern __shared__ int32_t sidx[];
-  for (int i = threadIdx.x; i < B * L; i += 256) sidx[i] = idx[i];
-  __syncthreads();
+  stage_indices(idx, sidx, B * L, K, bad_index);
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -74,7 +102,10 @@ __global__ __launch_bounds__(256) void embedding_bag_bwd_kernel(const float* dz,
   for (int b = 0; b < B; ++b) {
     const float g = dz[(long)b * M + m];
     sb += g;
-    for (int l = lane; l < L; l += 64) w[(long)l * K + sidx[b * L + l]] += g;   // same (l, column) from two samples: same lane, in order
+    for (int l = lane; l < L; l += 64) {     // same (l, column) from two samples: same lane, in order
+      const int k = sidx[b * L + l];
+      if (k >= 0) w[(long)l * K + k] += g;
+    }
   }
   if (dbias && lane == 0) dbias[m] = accumulate_bias ? dbias[m] + sb : sb;
 }
@@ -92,24 +123,33 @@ extern "C" int alvq_onehot_to_index_f32(const float* encodings, int32_t* idx, in
   return check_launch("alvq_onehot_to_index_f32");
 }
 
+extern "C" int alvq_indices_to_i32(const int64_t* idx, int32_t* out, int* bad_index, int64_t n, int K, void* stream) {
+  ALVQ_REQUIRE(idx && out && bad_index, ALVQ_EINVAL, "alvq_indices_to_i32: null pointer");
+  ALVQ_REQUIRE(n > 0 && K > 0, ALVQ_EINVAL, "alvq_indices_to_i32: bad dims");
+  long g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(indices_to_i32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, idx, out, bad_index, (long)n, K);
+  return check_launch("alvq_indices_to_i32");
+}
+
 extern "C" int alvq_embedding_bag_fwd_f32(const float* W, const float* bias, const int32_t* idx, float* out, int B, int L, int K,
-                                          int M, void* stream) {
+                                          int M, int* bad_index, void* stream) {
   ALVQ_REQUIRE(W && idx && out, ALVQ_EINVAL, "alvq_embedding_bag_fwd_f32: null pointer");
   ALVQ_REQUIRE(B > 0 && L > 0 && K > 0 && M > 0, ALVQ_EINVAL, "alvq_embedding_bag_fwd_f32: bad dims");
   ALVQ_REQUIRE((long)B * L * 4 <= 64 * 1024, ALVQ_EUNSUPPORTED, "alvq_embedding_bag_fwd_f32: B*L = %ld indices exceed the 64 KB LDS table",
                (long)B * L);
   hipLaunchKernelGGL(embedding_bag_fwd_kernel, dim3((M + 3) / 4), dim3(256), (size_t)B * L * 4, (hipStream_t)stream, W, bias, idx, out,
-                     B, L, K, M);
+                     B, L, K, M, bad_index);
   return check_launch("alvq_embedding_bag_fwd_f32");
 }
 
 extern "C" int alvq_embedding_bag_bwd_f32(const float* dz, const int32_t* idx, float* dW, float* dbias, int B, int L, int K, int M,
-                                          int accumulate_bias, void* stream) {
+                                          int accumulate_bias, int* bad_index, void* stream) {
   ALVQ_REQUIRE(dz && idx && dW, ALVQ_EINVAL, "alvq_embedding_bag_bwd_f32: null pointer");
   ALVQ_REQUIRE(B > 0 && L > 0 && K > 0 && M > 0, ALVQ_EINVAL, "alvq_embedding_bag_bwd_f32: bad dims");
   ALVQ_REQUIRE((long)B * L * 4 <= 64 * 1024, ALVQ_EUNSUPPORTED, "alvq_embedding_bag_bwd_f32: B*L = %ld indices exceed the 64 KB LDS table",
                (long)B * L);
   hipLaunchKernelGGL(embedding_bag_bwd_kernel, dim3((M + 3) / 4), dim3(256), (size_t)B * L * 4, (hipStream_t)stream, dz, idx, dW, dbias,
-                     B, L, K, M, accumulate_bias);
+                     B, L, K, M, accumulate_bias, bad_index);
   return check_launch("alvq_embedding_bag_bwd_f32");
 }

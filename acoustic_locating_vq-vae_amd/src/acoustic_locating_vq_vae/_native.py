@@ -92,8 +92,9 @@ _SIGNATURES = {
     "alvq_conv1d_wgrad_bf16x3_splits": (_i32, [_i32] * 6),
     "alvq_conv1d_wgrad_f16mx_splits": (_i32, [_i32] * 6),
     "alvq_onehot_to_index_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
-    "alvq_embedding_bag_fwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 4 + [_c_void_p]),
-    "alvq_embedding_bag_bwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 5 + [_c_void_p]),
+    "alvq_indices_to_i32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
+    "alvq_embedding_bag_fwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 4 + [_c_void_p] * 2),
+    "alvq_embedding_bag_bwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 5 + [_c_void_p] * 2),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -346,26 +347,64 @@ def onehot_to_index(enc):
     return idx, flag
 
 
-def embedding_bag_fwd(W, bias, idx, L, K):
-    """out (B, M) = bias + sum_l W[:, l*K + idx[b, l]];  W (M, L*K) fp32, idx (B, L) int32."""
+BAG_MAX_INDICES = 16384          # indices per embedding-bag launch (its 64 KB LDS table); larger batches are chunked over B
+
+
+def device_flag(device):
+    """A zeroed sticky int32 flag on the device (out-of-range indices, ...)."""
+    flag = torch.empty((1,), device=device, dtype=torch.float32)
+    fill_(flag, 0.0)                                 # bit pattern 0 == int 0
+    return flag.view(torch.int32)
+
+
+def indices_to_i32(idx, K, flag):
+    """int64 indices -> int32 with the range check a plain cast lacks; ORs 1 into ``flag`` for any value outside [0, K)."""
+    out = torch.empty(idx.shape, device=idx.device, dtype=torch.int32)
+    _check(lib().alvq_indices_to_i32(_ptr(idx, torch.int64, "idx"), out.data_ptr(), flag.data_ptr(), idx.numel(), K, _stream()),
+           "alvq_indices_to_i32")
+    return out
+
+
+def embedding_bag_fwd(W, bias, idx, L, K, flag=None):
+    """out (B, M) = bias + sum_l W[:, l*K + idx[b, l]];  W (M, L*K) fp32, idx (B, L) int32.  ``flag``: sticky device int
+    that receives 1 if an index lies outside [0, K) (such terms contribute nothing).  Any B: chunked over samples."""
     B = idx.shape[0]
     M = W.shape[0]
     if W.shape[1] != L * K or tuple(idx.shape) != (B, L):
         raise RuntimeError("embedding_bag_fwd: W %s / idx %s do not match L=%d, K=%d" % (tuple(W.shape), tuple(idx.shape), L, K))
+    if L > BAG_MAX_INDICES:
+        raise RuntimeError("embedding_bag_fwd: L = %d exceeds the %d-index table" % (L, BAG_MAX_INDICES))
     out = torch.empty((B, M), device=W.device, dtype=torch.float32)
-    _check(lib().alvq_embedding_bag_fwd_f32(_ptr(W, name="W"), _ptr(bias, name="bias"), _ptr(idx, torch.int32, "idx"), _ptr(out),
-                                            B, L, K, M, _stream()), "alvq_embedding_bag_fwd_f32")
+    step = max(1, BAG_MAX_INDICES // L)
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        _check(lib().alvq_embedding_bag_fwd_f32(_ptr(W, name="W"), _ptr(bias, name="bias"), _ptr(idx[b0:b0 + nb], torch.int32, "idx"),
+                                                _ptr(out[b0:b0 + nb]), nb, L, K, M, flag.data_ptr() if flag is not None else None,
+                                                _stream()), "alvq_embedding_bag_fwd_f32")
     return out
 
 
-def embedding_bag_bwd(dz, idx, L, K, want_bias=True):
-    """(dW (M, L*K) dense with the touched columns filled, dbias (M,)) from dz (B, M) and idx (B, L) int32."""
+def embedding_bag_bwd(dz, idx, L, K, want_bias=True, flag=None, dW_out=None, db_out=None):
+    """(dW (M, L*K) dense with the touched columns filled, dbias (M,)) from dz (B, M) and idx (B, L) int32.
+    ``dW_out`` / ``db_out``: accumulate into these (a zeroed gradient sink) instead of fresh tensors."""
     B, M = dz.shape
-    dW = torch.empty((M, L * K), device=dz.device, dtype=torch.float32)
-    fill_(dW, 0.0)
-    db = torch.empty((M,), device=dz.device, dtype=torch.float32) if want_bias else None
-    _check(lib().alvq_embedding_bag_bwd_f32(_ptr(dz, name="dz"), _ptr(idx, torch.int32, "idx"), _ptr(dW), _ptr(db), B, L, K, M, 0,
-                                            _stream()), "alvq_embedding_bag_bwd_f32")
+    if dW_out is not None:
+        if tuple(dW_out.shape) != (M, L * K):
+            raise RuntimeError("embedding_bag_bwd: dW_out has shape %s, expected %s" % (tuple(dW_out.shape), (M, L * K)))
+        dW = dW_out
+    else:
+        dW = torch.empty((M, L * K), device=dz.device, dtype=torch.float32)
+        fill_(dW, 0.0)
+    db = None
+    if want_bias:
+        db = db_out if db_out is not None else torch.empty((M,), device=dz.device, dtype=torch.float32)
+    step = max(1, BAG_MAX_INDICES // L)
+    for b0 in range(0, B, step):                     # later chunks accumulate into the same dW / dbias
+        nb = min(step, B - b0)
+        _check(lib().alvq_embedding_bag_bwd_f32(_ptr(dz[b0:b0 + nb], name="dz"), _ptr(idx[b0:b0 + nb], torch.int32, "idx"), _ptr(dW), _ptr(db),
+                                                nb, L, K, M, int(b0 > 0 or db_out is not None),
+                                                flag.data_ptr() if flag is not None else None, _stream()),
+               "alvq_embedding_bag_bwd_f32")
     return dW, db
 
 

@@ -27,21 +27,28 @@ class _EmbeddingBagLinearFn(torch.autograd.Function):
     """fc_1 on one-hot rows: out = bias + sum_l W[:, l*K + idx[b, l]]."""
 
     @staticmethod
-    def forward(ctx, idx, weight, bias, L, K):
+    def forward(ctx, idx, weight, bias, L, K, flag=None):
         ctx.save_for_backward(idx)
         ctx.L, ctx.K, ctx.has_bias = L, K, bias is not None
-        return N.embedding_bag_fwd(weight, bias, idx, L, K)
+        ctx.weight_ref, ctx.bias_ref = weight, bias               # looked up in the gradient sinks by the backward
+        return N.embedding_bag_fwd(weight, bias, idx, L, K, flag)
 
     @staticmethod
     def backward(ctx, dz):
         (idx,) = ctx.saved_tensors
         dW = db = None
         if ctx.needs_input_grad[1]:
+            # inside a train_step.LocationTrainer step the scatter-add goes straight into fc_1's slice of the (already
+            # zeroed) flat gradient buffer: no 843 MB temporary, no dense "grad += dW" pass by autograd
+            sink_w, sink_b = _ops._sink(ctx.weight_ref), (_ops._sink(ctx.bias_ref) if ctx.has_bias else None)
+            if sink_w is not None and (not ctx.has_bias or sink_b is not None):
+                N.embedding_bag_bwd(dz.contiguous(), idx, ctx.L, ctx.K, want_bias=ctx.has_bias, dW_out=sink_w, db_out=sink_b)
+                return None, None, None, None, None, None
             dW, db = N.embedding_bag_bwd(dz.contiguous(), idx, ctx.L, ctx.K,
                                          want_bias=ctx.has_bias and ctx.needs_input_grad[2])
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = dz.sum(dim=0)
-        return None, dW, db, None, None
+        return None, dW, db, None, None, None
 
 
 class LocationModule(nn.Module):
@@ -66,11 +73,25 @@ class LocationModule(nn.Module):
         if not torch.is_floating_point(x):                         # (B, L) code indices
             if x.dim() != 2 or x.shape[1] != L:
                 raise RuntimeError("LocationModule: an index input must be (B, %d), got %s" % (L, tuple(x.shape)))
-            return _EmbeddingBagLinearFn.apply(x.to(torch.int32).contiguous(), w, b, L, K)
+            # caller-supplied indices are range-checked on the device (the kernels skip and flag an index outside
+            # [0, K) instead of reading / writing out of bounds; a 64-bit value is checked BEFORE it is narrowed) and the
+            # flag is read back here -- one sync, like the one-hot path's -- so that bad input raises as
+            # torch.nn.functional.embedding_bag does
+            flag = N.device_flag(x.device)
+            if x.dtype == torch.int64:
+                idx = N.indices_to_i32(x.contiguous(), K, flag)
+            elif x.dtype == torch.int32:
+                idx = x.contiguous()
+            else:
+                raise RuntimeError("LocationModule: index input must be int32 or int64, got %s" % x.dtype)
+            out = _EmbeddingBagLinearFn.apply(idx, w, b, L, K, flag)
+            if int(flag.item()) != 0:
+                raise IndexError("LocationModule: a code index lies outside [0, %d)" % K)
+            return out
         flat = torch.flatten(x, start_dim=1)
         if flat.shape[1] != L * K:
             return self.fc_1(flat)                                 # raises the reference's own shape error
-        if not x.requires_grad and x.shape[0] * L <= 16384:
+        if not x.requires_grad:
             idx, flag = N.onehot_to_index(_ops.dense(flat).view(-1, K))
             if int(flag.item()) == 0:                              # every row exactly one-hot: the sparse evaluation
                 return _EmbeddingBagLinearFn.apply(idx.view(-1, L), w, b, L, K)

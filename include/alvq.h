@@ -337,14 +337,20 @@ int alvq_conv1d_wgrad_f16mx_splits(int B, int C, int M, int L, int KW, int nseg)
  * it) is OR-ed with 1 if any row is not exactly one-hot (then the caller must fall back to the dense product).
  * Inverse of alvq_onehot_f32 for the value get_latent_representation returns (vector_quantizer.py:39-40,58). */
 int alvq_onehot_to_index_f32(const float* encodings, int32_t* idx, int* not_onehot, int64_t rows, int K, void* stream);
+/* out[i] = (int32) idx[i] for n int64 indices; a value outside [0, K) becomes -1 and ORs 1 into *bad_index (device int,
+ * caller-zeroed, sticky) -- a plain narrowing cast would wrap 2^32 + 5 to 5. */
+int alvq_indices_to_i32(const int64_t* idx, int32_t* out, int* bad_index, int64_t n, int K, void* stream);
 /* out[b][m] = bias[m] + sum_l W[m][l*K + idx[b][l]]      W: (M, L*K) row-major (nn.Linear.weight), idx: (B, L),
- * out: (B, M); sums in a fixed order.  Replaces F.linear at location_model.py:21 for one-hot x.  B*L <= 16384. */
+ * out: (B, M); sums in a fixed order.  Replaces F.linear at location_model.py:21 for one-hot x.  B*L <= 16384 per call
+ * (callers chunk over B).  An index outside [0, K) contributes nothing and ORs 1 into *bad_index (optional device int,
+ * sticky, caller-zeroed): no out-of-bounds access; the caller raises, as torch's embedding_bag does. */
 int alvq_embedding_bag_fwd_f32(const float* W, const float* bias, const int32_t* idx, float* out,
-                               int B, int L, int K, int M, void* stream);
+                               int B, int L, int K, int M, int* bad_index, void* stream);
 /* dW[m][l*K + idx[b][l]] += dz[b][m] for every (b, l) -- the caller zero-fills dW (M, L*K) first (alvq_fill_f32) --
- * and dbias[m] (+)= sum_b dz[b][m].  One wave owns a weight row: no atomics, fixed order. */
+ * and dbias[m] (+)= sum_b dz[b][m].  One wave owns a weight row: no atomics, fixed order.  Out-of-range indices are
+ * skipped and flagged as in the forward. */
 int alvq_embedding_bag_bwd_f32(const float* dz, const int32_t* idx, float* dW, float* dbias,
-                               int B, int L, int K, int M, int accumulate_bias, void* stream);
+                               int B, int L, int K, int M, int accumulate_bias, int* bad_index, void* stream);
 
 #ifdef __cplusplus
 }

@@ -149,3 +149,86 @@ def test_location_training_loop_tracks_oracle():
     # few steps although every loss above agreed to 1e-4.  Training did move every layer:
     for k, v in m.named_parameters():
         assert float((v.detach().cpu() - p[k]).abs().max()) > 0, k
+
+
+def test_index_input_is_range_checked_and_any_batch_size_runs():
+    """Round-2 advisor finding: caller-supplied (B, L) indices reached the kernels unchecked (out-of-bounds read in the
+    forward, out-of-bounds += into the 843 MB gradient in the backward; an int64 such as 2^32 + 5 wrapped to 5) and
+    B * L > 16384 was a hard error.  Now: the kernels skip and flag such an index, the module raises like torch's
+    embedding_bag, 64-bit indices are checked before they are narrowed, and large batches are chunked over samples."""
+    from acoustic_locating_vq_vae.vq_vae.location_model.location_model import LocationModule
+    torch.manual_seed(0)
+    L, K = 13, 32
+    m = LocationModule(L, K, 2).cuda()
+    good = torch.randint(0, K, (4, L))
+    ref = m(LO.onehot_codes(good, K).cuda())                      # the one-hot form is the specification
+    for dt in (torch.int32, torch.int64):
+        assert rel(m(good.to(dt).cuda()), ref) < 1e-5
+    for bad_value, dt in ((-1, torch.int32), (K, torch.int32), (K, torch.int64), (-3, torch.int64), ((1 << 32) + 5, torch.int64)):
+        bad = good.clone().to(dt)
+        bad[2, 7] = bad_value
+        with pytest.raises(IndexError, match="outside"):
+            m(bad.cuda())
+    with pytest.raises(RuntimeError, match="int32 or int64"):
+        m(good.to(torch.int16).cuda())
+    # the raw kernels: a flagged index contributes nothing and nothing outside dW is written
+    W = torch.randn(8, L * K).cuda()
+    idx = good.int().cuda()
+    idx[0, 0] = K + 1000
+    flag = N.device_flag("cuda")
+    out = N.embedding_bag_fwd(W, None, idx, L, K, flag)
+    assert int(flag.item()) == 1
+    want = LO.onehot_codes(good, K).flatten(1).cuda()
+    want[0, :K] = 0                                               # sample 0 lost its l = 0 term
+    assert rel(out, want @ W.t()) < 1e-5
+    flag2 = N.device_flag("cuda")
+    dW, _ = N.embedding_bag_bwd(torch.ones(4, 8).cuda(), idx, L, K, flag=flag2)
+    assert int(flag2.item()) == 1 and float(dW.sum()) == 8.0 * (4 * L - 1)
+    # B * L beyond one launch's index table: chunked over samples, forward and backward
+    B = N.BAG_MAX_INDICES // L + 37
+    big = torch.randint(0, K, (B, L))
+    m.zero_grad()
+    y = m(big.cuda())
+    y.square().mean().backward()
+    g_sparse = m.fc_1.weight.grad.clone()
+    m.zero_grad()
+    y2 = m(LO.onehot_codes(big, K).cuda().requires_grad_(True))   # requires_grad: forces the dense product
+    y2.square().mean().backward()
+    assert rel(y, y2) < 1e-5 and rel(g_sparse, m.fc_1.weight.grad) < 1e-4
+
+
+@pytest.mark.parametrize("form", ["onehot", "indices"])
+def test_location_trainer_flat_adam_tracks_oracle(form):
+    """train_step.LocationTrainer -- the script's step with the optimiser as one HIP launch over a flat buffer and fc_1's
+    gradient scattered straight into it -- against torch.optim.Adam on the CPU oracle: same loss curve, and after ONE
+    step (before ReLU-edge units make individual parameters incomparable) the same parameters."""
+    from acoustic_locating_vq_vae.train_step import LocationTrainer
+    L, K, od, B = 21, 32, 1, 8
+    p = LO.closed_form_location_params(LO.location_param_shapes(L, K, od), gain=3.0)
+    m = module(L, K, od, p).train()
+    tr = LocationTrainer(m, lr=1e-3)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    opt_o = torch.optim.Adam(list(po.values()), lr=1e-3)
+    for step in range(4):
+        idx = LO.hashed_indices(B, L, K, 40 + step)
+        theta = torch.from_numpy(O.hashed_uniform(B, 50 + step, 3.0))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt_o.zero_grad()
+            want = LO.location_loss(LO.location_forward(LO.onehot_codes(idx, K), po), theta)
+            want.backward()
+            opt_o.step()
+            codes = LO.onehot_codes(idx, K).cuda() if form == "onehot" else torch.from_numpy(idx).cuda()
+            got = tr.step(codes, theta)
+        assert abs(float(got) - float(want)) < 1e-4 * abs(float(want)) + 1e-7, (step, float(got), float(want))
+        if step == 0:
+            for k, v in m.named_parameters():
+                assert rel(v, po[k]) < 1e-5, k
+    # untouched columns of fc_1 received a zero gradient and (first moment zero) did not move; touched ones did
+    w0, w1 = p["fc_1.weight"], m.fc_1.weight.detach().cpu()
+    moved = (w1 != w0).any(dim=0)
+    touched = torch.zeros(L * K, dtype=torch.bool)
+    for step in range(4):
+        idx = LO.hashed_indices(B, L, K, 40 + step)
+        touched[(np.arange(L)[None, :] * K + idx).reshape(-1)] = True
+    assert torch.equal(moved, touched)
