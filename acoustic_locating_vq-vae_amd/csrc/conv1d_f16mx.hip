@@ -490,11 +490,22 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
 }
 
 // ------------------------------------------------------------------------------------------------ boundary conversions
+// Sticky range flag of the format (one int per device, in the code object's own data segment -- not an allocation):
+// bit 0 = a value of magnitude >= 65504 (fp16's largest finite value; it was stored saturated), bit 1 = a NaN, seen by a
+// conversion INTO the format (model inputs, gradients entering a backward chain).  Read / cleared by alvq_f16mx_range_flag.
+__device__ int g_fx_range_flag = 0;
+
+__global__ void fx_range_flag_kernel(int* out, int reset) {
+  *out = g_fx_range_flag;
+  if (reset) g_fx_range_flag = 0;
+}
+
 // (B,C,L) fp32 -> f16mx NLC planes, optionally multiplied by a device scalar (the loss scale of a backward chain)
 __global__ __launch_bounds__(256) void ncl_to_nlc_fx_kernel(const float* x, u16* y, long plane, int B, int C, int L, int Cp,
                                                             int rows_total, int e, const float* scale) {
   __shared__ float tile[32][33];
   fx_saturating_conversions();
+  int range = 0;
   const int ct = Cp / 32;
   const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -505,7 +516,13 @@ __global__ __launch_bounds__(256) void ncl_to_nlc_fx_kernel(const float* x, u16*
     const int c = c0 + ty + 8 * i, row = r0 + tx;
     int b, l;
     const bool ok = row_valid(row, Lp1, ndata, &b, &l) && c < C;
-    tile[ty + 8 * i][tx] = ok ? x[((long)b * C + c) * L + l] * sc : 0.f;
+    const float v = ok ? x[((long)b * C + c) * L + l] * sc : 0.f;
+    tile[ty + 8 * i][tx] = v;
+    range |= (fabsf(v) >= 65504.f ? 1 : 0) | (v != v ? 2 : 0);
+  }
+  if (__any(range)) {                       // rare: one atomic per wave that saw such a value
+    for (int o = 32; o > 0; o >>= 1) range |= __shfl_xor(range, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicOr(&g_fx_range_flag, range);
   }
   __syncthreads();
   // thread (row = tid >> 3, 4 channels at (tid & 7) * 4): 8 bytes of H, 4 of hi8, 4 of lo8
@@ -660,6 +677,12 @@ extern "C" int alvq_nlc_to_ncl_f16mx(const void* x, float* y, int B, int C, int 
   hipLaunchKernelGGL(nlc_to_ncl_fx_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, (const u16*)x,
                      nlc_plane_elems(B, L, C), y, B, C, L, Cp, rows, FX_E_ACT, scale);
   return check_launch("alvq_nlc_to_ncl_f16mx");
+}
+
+extern "C" int alvq_f16mx_range_flag(int* out, int reset, void* stream) {
+  ALVQ_REQUIRE(out, ALVQ_EINVAL, "alvq_f16mx_range_flag: null pointer");
+  hipLaunchKernelGGL(fx_range_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out, reset);
+  return check_launch("alvq_f16mx_range_flag");
 }
 
 extern "C" int alvq_relu_mask_f16mx(const void* dy, const void* t, void* out, int B, int C, int L, void* stream) {

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "alvq_conv1d_wgrad_bf16x3_workspace_bytes": (_i64, [_i32] * 5),
     "alvq_conv1d_wgrad_bf16x3": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p]),
     "alvq_grad_scale_f32": (_i32, [_c_void_p, _i64, _c_void_p, _c_void_p]),
+    "alvq_f16mx_range_flag": (_i32, [_c_void_p, _i32, _c_void_p]),
     "alvq_ncl_to_nlc_f16mx": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p]),
     "alvq_nlc_to_ncl_f16mx": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p]),
     "alvq_relu_mask_f16mx": (_i32, [_c_void_p] * 3 + [_i32, _i32, _i32, _c_void_p]),
@@ -629,6 +630,16 @@ def grad_scale(x):
     fill_(state, 0.0)
     _check(lib().alvq_grad_scale_f32(_ptr(x, name="x"), x.numel(), state.data_ptr(), _stream()), "alvq_grad_scale_f32")
     return state
+
+
+def f16mx_range_flag(reset=True, device="cuda"):
+    """Sticky range flag of the f16mx format on the current device (one host sync): bit 0 = a value >= 65504 in magnitude
+    entered the format (it was stored saturated), bit 1 = a NaN did.  f16mx carries fp16's range: the precondition is
+    |activations| < 65504 (standardised spectrograms and Kaiming-scale weights stay orders of magnitude below); gradients
+    are brought into range by the device-chosen loss scale."""
+    out = device_flag(torch.device(device))
+    _check(lib().alvq_f16mx_range_flag(out.data_ptr(), int(bool(reset)), _stream()), "alvq_f16mx_range_flag")
+    return int(out.item())
 
 
 def _nlc_ptr(t, ref, C, name):

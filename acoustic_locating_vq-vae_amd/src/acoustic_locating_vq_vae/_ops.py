@@ -21,8 +21,11 @@ Two precisions share these chains through a small "engine" object:
   rate); ~1.5e-5 per product, same parity class as bf16x3 at ~2/3 of its matrix time.  Gradients run under a
   power-of-two loss scale chosen on the device (csrc/f16mx_common.h).
 
-Select with ``set_compute_dtype("f32" | "bf16" | "bf16x3" | "f16mx")`` or the environment variable ``ALVQ_DTYPE``
-(default f32).
+Select with ``set_compute_dtype("f32" | "bf16" | "bf16x3" | "f16mx")`` or the environment variable ``ALVQ_DTYPE``.
+DEFAULT (round 3): ``f16mx`` -- the fastest mode that holds the reference's forward results (codebook indices bit-exact,
+outputs within 2e-5 on the default-config goldens), so that ``scripts/train_speech.py`` unchanged runs at ~5x the
+``f32`` mode's rate.  ``ALVQ_DTYPE=f32`` selects the exact-fp32 MFMA mode (strict gradient parity, 1e-6).  f16mx carries
+fp16's range: activations must stay below 65504 (``_native.f16mx_range_flag()`` reports inputs that do not).
 """
 from __future__ import annotations
 
@@ -35,7 +38,10 @@ from . import _native as N
 
 OIK, IOK = N.W_OIK, N.W_IOK
 
-_DTYPE = os.environ.get("ALVQ_DTYPE", "f32")
+DEFAULT_DTYPE = "f16mx"
+_DTYPE = os.environ.get("ALVQ_DTYPE", DEFAULT_DTYPE)
+if _DTYPE not in ("f32", "bf16", "bf16x3", "f16mx"):
+    raise ValueError("ALVQ_DTYPE must be 'f32', 'bf16', 'bf16x3' or 'f16mx', got %r" % (_DTYPE,))
 
 
 def set_compute_dtype(name):
@@ -97,9 +103,19 @@ def _sink(t):
 # a model evaluated after training never sees a stale image.
 # ---------------------------------------------------------------------------------------------------
 class PackPool:
-    def __init__(self, params):
+    """``dynamic``: the parameters the trainer's optimiser updates every step -- their images are refreshed by the step's
+    batched launch.  Every other conv weight of the model (the frozen encoders of the echoed config) is STATIC: packed at
+    first use and again only when its version counter says it changed (``refresh_static``, called by the trainer outside
+    any graph capture) -- round 2 re-packed ~30 MB of never-changing encoder weights on every echoed step."""
+
+    def __init__(self, params, dynamic=None):
         self._eligible = {p.data_ptr(): p for p in params if p.dim() == 3}
+        self._dynamic = None if dynamic is None else {p.data_ptr() for p in dynamic}
         self._entries = {}          # (data_ptr, layout, planes) -> (packed image, tag)
+        self._static_version = {}   # key -> parameter version the static image was packed at
+
+    def _is_static(self, ptr):
+        return self._dynamic is not None and ptr not in self._dynamic
 
     def lookup(self, w, layout, planes):
         key = (w.data_ptr(), layout, planes)
@@ -113,17 +129,77 @@ class PackPool:
         img, tag = N.packed_weight_alloc(p.detach(), layout, planes)
         N.pack_weights_batch([(p.detach(), img, layout)], planes)
         self._entries[key] = (img, tag)
+        if self._is_static(key[0]):
+            self._static_version[key] = p._version
         return self._entries[key]
 
-    def refresh(self):
+    def _refresh(self, keys):
         by_planes = {}
-        for (ptr, layout, planes), (img, _) in self._entries.items():
-            by_planes.setdefault(planes, []).append((self._eligible[ptr].detach(), img, layout))
+        for key in keys:
+            ptr, layout, planes = key
+            by_planes.setdefault(planes, []).append((self._eligible[ptr].detach(), self._entries[key][0], layout))
         for planes, entries in by_planes.items():
             N.pack_weights_batch(entries, planes)
 
+    def refresh(self):
+        """The step's batched re-pack: every image of a parameter the optimiser just updated."""
+        self._refresh([k for k in self._entries if not self._is_static(k[0])])
+
+    def refresh_static(self):
+        """Host-side check, outside graph capture: re-pack a static image whose parameter was modified since."""
+        stale = [k for k, v in self._static_version.items() if self._eligible[k[0]]._version != v]
+        if stale:
+            self._refresh(stale)
+            for k in stale:
+                self._static_version[k] = self._eligible[k[0]]._version
+
 
 _ACTIVE_POOL = None
+
+# ---------------------------------------------------------------------------------------------------
+# packed-weight cache for everything OUTSIDE a Trainer step (SURVEY 8b "Ownership": caller-owned re-layouts, cached and
+# invalidated by the parameter's version counter): the script loop (model(x); loss.backward(); torch.optim.Adam.step())
+# packs each (weight, layout) once per optimiser step instead of once per use, and a model whose weights do not change --
+# evaluation, the frozen encoders of the echoed model -- packs them once.  An entry is valid only for the SAME tensor
+# object (weak reference: a new parameter that reuses a freed one's address never hits) at the SAME ``_version`` (every
+# in-place update torch knows about bumps it: optimizer.step, load_state_dict, copy_) and the same weight epoch
+# (``bump_weight_epoch``: the HIP optimiser writes parameter memory behind torch's back).  Writes through ``.data`` are
+# invisible to the version counter -- as they are to autograd -- call ``invalidate_packed_weights()`` after them.
+# ---------------------------------------------------------------------------------------------------
+_PACK_CACHE = {}
+_WEIGHT_EPOCH = 0
+PACK_CACHE_STATS = {"hits": 0, "packs": 0}
+
+
+def bump_weight_epoch():
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def invalidate_packed_weights():
+    _PACK_CACHE.clear()
+
+
+def _cached_pack(w, layout, wplanes):
+    if os.environ.get("ALVQ_PACK_CACHE", "1") == "0":
+        return N.pack_weight(w.detach(), layout, wplanes)
+    key = (w.data_ptr(), layout, wplanes)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        ref, version, epoch, shape, packed = hit
+        if ref() is w and version == w._version and epoch == _WEIGHT_EPOCH and shape == w.shape:
+            PACK_CACHE_STATS["hits"] += 1
+            return packed
+    if len(_PACK_CACHE) > 512:                       # dead entries of discarded models
+        for k in [k for k, v in _PACK_CACHE.items() if v[0]() is None]:
+            del _PACK_CACHE[k]
+    packed = N.pack_weight(w.detach(), layout, wplanes)
+    PACK_CACHE_STATS["packs"] += 1
+    try:
+        _PACK_CACHE[key] = (weakref.ref(w), w._version, _WEIGHT_EPOCH, w.shape, packed)
+    except TypeError:
+        pass
+    return packed
 
 # two-part backward (train_step.Trainer): while a list is installed here, ConvolutionalVQVAE.forward hands the
 # encoder output over as a detached leaf and records (graph output, leaf) so the trainer can run
@@ -238,19 +314,16 @@ class _BF16Engine:
     wplanes = 1         # format code of a packed weight (alvq_pack_weights_bf16_batch)
     fmt = "bf16"
 
-    def __init__(self):
-        self._packed = {}
-
     def _w(self, w, layout):
         if _ACTIVE_POOL is not None:
             hit = _ACTIVE_POOL.lookup(w, layout, self.wplanes)
             if hit is not None:
                 return hit
-        key = (w.data_ptr(), layout)
-        pk = self._packed.get(key)
-        if pk is None:
-            pk = self._packed[key] = N.pack_weight(w.detach(), layout, self.wplanes)
-        return pk
+        if torch.cuda.is_current_stream_capturing():
+            # inside a user's own graph capture a cache hit would freeze a packed image into the graph while later
+            # replays expect fresh weights: pack in the graph, every time
+            return N.pack_weight(w.detach(), layout, self.wplanes)
+        return _cached_pack(w, layout, self.wplanes)
 
     def enter(self, x, grad=False):
         """fp32 (B,C,L) -> the engine's layout.  ``grad``: x is a gradient entering a backward chain (only the f16mx

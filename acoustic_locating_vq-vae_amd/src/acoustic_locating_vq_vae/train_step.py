@@ -142,6 +142,7 @@ class FlatAdam:
                 N.adam_step_dev(self.b.flat[lo:s_lo], self.b.grad[lo:s_lo], self.exp_avg[lo:s_lo],
                                 self.exp_avg_sq[lo:s_lo], self.scalars, self.betas[0], self.betas[1], self.eps)
             lo = max(lo, s_hi)
+        _ops.bump_weight_epoch()        # parameter memory changed behind torch's version counters: packed images are stale
 
     def step(self, grad_scale=1.0):
         self.prepare(grad_scale)
@@ -219,7 +220,7 @@ class Trainer:
         # every conv weight of the model (frozen sub-models of the echoed config included) keeps persistent packed
         # bf16 images, refreshed by one launch per step
         use_pool = self.buffers.flat.is_cuda and os.environ.get("ALVQ_PACK_POOL", "1") != "0"
-        self.pack_pool = _ops.PackPool(list(model.parameters())) if use_pool else None
+        self.pack_pool = _ops.PackPool(list(model.parameters()), dynamic=self.buffers.params) if use_pool else None
         self.buffers.broadcast_params(group=group)
         self.opt = FlatAdam(self.buffers, lr=lr)
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -350,6 +351,8 @@ class Trainer:
         Order on the stream:  part 1 (fwd + decoder/quantiser backward)  ->  all-reduce(early bucket) starts  ->
         part 2 (encoder backward) runs while it is in flight  ->  all-reduce(late bucket)  ->  Adam."""
         self._check_frozen()
+        if self.pack_pool is not None:
+            self.pack_pool.refresh_static()        # frozen weights (echoed encoders): re-packed only if someone changed them
         if self._graph is None:
             self.opt.prepare(self.grad_scale)
             out = self._body(raw, wiener)

@@ -307,8 +307,14 @@ int alvq_conv1d_wgrad_bf16x3_splits(int B, int C, int M, int L, int KW, int nseg
  *   alvq_conv1d_f16mx      y_ncl output multiplied by *out_scale (NULL = 1); mask_bits / relu_bits_out as in
  *                          alvq_conv1d_bf16 (one bit per element, [rows][Mp/8] bytes, bit = stored H > 0)
  *   alvq_conv1d_wgrad_f16mx  dw / dbias multiplied by *inv_scale (NULL = 1)
+ *   alvq_f16mx_range_flag  *out (device int) = the format's sticky range flag of the current device, optionally cleared:
+ *                          bit 0 = a value of magnitude >= 65504 entered the format (stored saturated: fp16 has no
+ *                          larger finite value), bit 1 = a NaN entered it.  Set by alvq_ncl_to_nlc_f16mx (model inputs
+ *                          and gradients entering a backward chain, after the loss scale).  Values produced INSIDE a
+ *                          chain saturate the same way but are not flagged (precondition: activations below 65504).
  * ============================================================================================== */
 int alvq_grad_scale_f32(const float* x, int64_t n, float* state, void* stream);
+int alvq_f16mx_range_flag(int* out, int reset, void* stream);
 int alvq_ncl_to_nlc_f16mx(const float* x, void* y, int B, int C, int L, const float* scale, void* stream);
 int alvq_nlc_to_ncl_f16mx(const void* x, float* y, int B, int C, int L, const float* scale, void* stream);
 int alvq_relu_mask_f16mx(const void* dy, const void* t, void* out, int B, int C, int L, void* stream);

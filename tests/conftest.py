@@ -25,6 +25,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 os.environ.setdefault("ALVQ_WIDE_MIN_TILES", "1")
 
 
+# The package's default compute mode is f16mx (the parity-holding fast mode).  Every test that is about a mode names it
+# (fixtures / set_compute_dtype); the tests that do not -- kernels and modules of the exact-fp32 path -- are written
+# against "f32", so that is the session's initial value.  tests/test_host_cpu.py checks the package default itself.
+os.environ.setdefault("ALVQ_DTYPE", "f32")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -203,6 +203,26 @@ def test_loss_scale_carries_gradients_of_any_magnitude(mag):
     assert rel(N.nlc_to_ncl(N.relu_mask_bf16(dyn, fx(x.new_ones(B, M, L)))), dy) < 1e-4
 
 
+def test_range_flag_reports_inputs_outside_fp16s_range():
+    """f16mx carries fp16's range (round-2 advisor finding: no overflow signal).  A value of magnitude >= 65504, or a NaN,
+    entering the format raises a sticky device flag (and is stored saturated, not as inf); in-range data leaves it clear."""
+    N.f16mx_range_flag(reset=True)
+    x = torch.randn(2, 40, 33).cuda() * 100
+    fx(x)
+    assert N.f16mx_range_flag(reset=False) == 0
+    x[1, 3, 5] = 7e4
+    back = N.nlc_to_ncl(fx(x))
+    assert N.f16mx_range_flag(reset=False) == 1 and float(back[1, 3, 5]) == 65504.0
+    assert N.f16mx_range_flag(reset=True) == 1 and N.f16mx_range_flag() == 0        # sticky until cleared
+    x[1, 3, 5] = float("nan")
+    fx(x)
+    assert N.f16mx_range_flag() == 2
+    # a gradient entering a backward chain is brought into range by its loss scale whatever its magnitude: no flag
+    g = torch.randn(2, 40, 33).cuda() * 1e7
+    fx(g, N.grad_scale(g))
+    assert N.f16mx_range_flag() == 0
+
+
 def test_relu_mask_f16mx():
     torch.manual_seed(4)
     d, t = torch.randn(2, 70, 33), torch.randn(2, 70, 33)

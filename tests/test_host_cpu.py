@@ -139,3 +139,20 @@ def test_overlay_resolves_non_hot_path_modules_from_the_reference():
     # this build does not provide (plotting) is found in the reference checkout
     assert lines[0].startswith(pkg) and lines[1].startswith(pkg) and lines[2].startswith(pkg)
     assert lines[4].startswith("/root/reference")
+
+
+def test_package_default_mode_is_the_parity_holding_fast_mode():
+    """A user who sets nothing (scripts/train_speech.py unchanged) gets f16mx; ALVQ_DTYPE overrides; junk is refused."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "acoustic_locating_vq-vae_amd")
+    code = "from acoustic_locating_vq_vae import _ops; print(_ops.get_compute_dtype(), _ops.DEFAULT_DTYPE)"
+    env = {k: v for k, v in os.environ.items() if k != "ALVQ_DTYPE"}
+    env["PYTHONPATH"] = os.pathsep.join([pkg, os.path.join(pkg, "src")])
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["f16mx", "f16mx"], out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, ALVQ_DTYPE="f32"), capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["f32", "f16mx"], out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, ALVQ_DTYPE="fp64"), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "ALVQ_DTYPE" in out.stderr

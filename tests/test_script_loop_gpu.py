@@ -131,3 +131,52 @@ def test_rir_script_loop_with_permuted_input_tracks_the_cpu_reference_path():
     sd = m.state_dict()
     for k, v in p_cpu.items():
         assert rel(sd[k], v.detach()) < 2e-3, k
+
+
+@pytest.mark.parametrize("dtype", ["f16mx", "bf16"])
+def test_packed_weight_cache_follows_the_version_counter(dtype, monkeypatch):
+    """Outside a Trainer the packed (weight, layout) images are cached per parameter VERSION: a training step packs each
+    image once (not once per use / per autograd node), an unchanged model (evaluation) packs nothing, every in-place update
+    torch knows about invalidates (optimizer.step, load_state_dict), a new model at a recycled address never hits, and
+    the results are bit-identical to packing on every use (ALVQ_PACK_CACHE=0)."""
+    from acoustic_locating_vq_vae import _ops
+    cfg = (20, 48, 8, 2, 24, 0.25, 64)
+    p0 = O.closed_form_params(O.vqvae_param_shapes(20, 48, 8, 24, 64), 0.8)
+    xs = [torch.from_numpy(O.hashed_uniform(3 * 20 * 33, 50 + i, 2.0).reshape(3, 20, 33)).cuda() for i in range(3)]
+    prev = _ops.get_compute_dtype()
+    _ops.set_compute_dtype(dtype)
+    try:
+        def run(cache):
+            monkeypatch.setenv("ALVQ_PACK_CACHE", "1" if cache else "0")
+            _ops.invalidate_packed_weights()
+            m = build(cfg, p0).train()
+            log = speech_loop(m, m.parameters(), xs, 3, jitter_seed=11)
+            return m, log
+        m_ref, log_ref = run(False)
+        _ops.PACK_CACHE_STATS.update(hits=0, packs=0)
+        m, log = run(True)
+        assert log == log_ref
+        for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
+            assert torch.equal(a, b), k
+        n_images = 10 + 9                     # 10 conv weights in their forward layout + 9 in the data-gradient layout (the
+        #                                       first encoder conv needs no gradient with respect to the input)
+        assert _ops.PACK_CACHE_STATS["packs"] == 3 * n_images, _ops.PACK_CACHE_STATS     # once per step, not per use
+        assert _ops.PACK_CACHE_STATS["hits"] > 0                                         # the shared residual weights' re-uses
+        # evaluation: the last optimiser step updated the weights, so the first forward packs the 10 forward images; after
+        # that nothing changes and nothing is packed
+        m.eval()
+        with torch.no_grad():
+            _ops.PACK_CACHE_STATS.update(hits=0, packs=0)
+            y1 = m(xs[0])[1]
+            first = _ops.PACK_CACHE_STATS["packs"]
+            y2 = m(xs[0])[1]
+            assert first == 10 and _ops.PACK_CACHE_STATS["packs"] == 10 and torch.equal(y1, y2)
+            # load_state_dict bumps the versions: the images are rebuilt and the output follows the new weights
+            m.load_state_dict(expand(p0, cfg[3]))
+            y3 = m(xs[0])[1]
+            assert _ops.PACK_CACHE_STATS["packs"] == 20 and not torch.equal(y3, y1)
+            fresh = build(cfg, p0).eval()
+            assert torch.equal(fresh(xs[0])[1], y3)
+    finally:
+        _ops.set_compute_dtype(prev)
+        _ops.invalidate_packed_weights()
