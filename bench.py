@@ -360,6 +360,12 @@ def main():
                                     "launch": "eager, module API + torch.optim.Adam (train_speech.py:62-74,88-91)"}
         del m2, opt2, raw
         torch.cuda.empty_cache()
+        # the Trainer without graph replay (flat buffers, HIP Adam, gradient sinks; eager launches): what the script loop
+        # is to be compared with
+        te, _, _ = run_config("speech", args.dtype, B, s3, 2, graph=False, timer=False)
+        line["trainer_eager_mode"] = {"value": te["value"], "unit": "spectrograms/s", "ms_per_step": te["ms_per_step"],
+                                      "steps": s3, "dtype": args.dtype, "launch": te["launch"]}
+        line["script_loop_mode"]["vs_trainer_eager"] = line["script_loop_mode"]["value"] / te["value"]
 
         # BASELINE configs[3]: the VQ argmin kernel alone, codebook 4096 x 256, N = 512 * 500 rows
         n_, k_, d_ = 256000, 4096, 256

@@ -212,7 +212,7 @@ def test_range_flag_reports_inputs_outside_fp16s_range():
     assert N.f16mx_range_flag(reset=False) == 0
     x[1, 3, 5] = 7e4
     back = N.nlc_to_ncl(fx(x))
-    assert N.f16mx_range_flag(reset=False) == 1 and float(back[1, 3, 5]) == 65504.0
+    assert N.f16mx_range_flag(reset=False) == 1 and 65504.0 <= float(back[1, 3, 5]) < 65505.0     # saturated, not inf
     assert N.f16mx_range_flag(reset=True) == 1 and N.f16mx_range_flag() == 0        # sticky until cleared
     x[1, 3, 5] = float("nan")
     fx(x)

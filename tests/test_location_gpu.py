@@ -222,8 +222,11 @@ def test_location_trainer_flat_adam_tracks_oracle(form):
             got = tr.step(codes, theta)
         assert abs(float(got) - float(want)) < 1e-4 * abs(float(want)) + 1e-7, (step, float(got), float(want))
         if step == 0:
+            # Adam's first step moves an entry by lr * sign(gradient): an entry whose gradient is 0 on one side and 1e-12
+            # on the other (a unit at the edge of its ReLU) differs by lr, so the comparison is "all but a handful agree"
             for k, v in m.named_parameters():
-                assert rel(v, po[k]) < 1e-5, k
+                d = (v.detach().cpu() - po[k].detach()).abs()
+                assert float((d > 1e-6).float().mean()) < 2e-3 and float(d.max()) <= 2.001e-3, (k, float(d.max()))
     # untouched columns of fc_1 received a zero gradient and (first moment zero) did not move; touched ones did
     w0, w1 = p["fc_1.weight"], m.fc_1.weight.detach().cpu()
     moved = (w1 != w0).any(dim=0)
