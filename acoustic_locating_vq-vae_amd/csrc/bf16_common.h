@@ -60,6 +60,10 @@ struct ConvBArgs {
   // its mask behind (bits_out), and a later data-gradient launch reads 1/16 of the bytes instead of the tensor (mask_bits)
   const unsigned char* mask_bits;
   unsigned char* bits_out;
+  // element type of every 16-bit operand and of the NLC output: 0 = bf16 (the throughput mode), 1 = fp16 (the backward
+  // pass of the f16mx_hb mode: gradients under a loss scale, the H planes of f16mx activations and packed weights)
+  int elem;
+  const float* out_scale;   // OUT == 1: device scalar multiplied into the fp32 output (undoes a loss scale), or null
 };
 
 constexpr int WP_ROWS = 256;   // packed weights are padded to this many rows per tap (largest m-tile)
@@ -77,6 +81,36 @@ __device__ __forceinline__ unsigned f2bf_pk(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
 }
 
+// ---- element type of the 16-bit pipeline (template parameter F16: 0 = bf16, 1 = fp16).  Same geometry, same MFMA shapes
+// and rates; what differs is the MFMA opcode and the conversions at the epilogues.
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+template <int F16>
+__device__ __forceinline__ float elem2f(u16 v) {
+  if (F16) return (float)__builtin_bit_cast(_Float16, v);
+  return bf2f(v);
+}
+// two floats -> packed pair, round-to-nearest-even (fp16: saturating at +-65504 under elem_saturate())
+template <int F16>
+__device__ __forceinline__ unsigned elem_pk(float lo, float hi) {
+  if (F16) {
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h16x2_t));
+  }
+  return f2bf_pk(lo, hi);
+}
+// fp16 conversions saturate instead of producing infinities: MODE.FP16_OVFL (see f16mx_common.h); once per wave, before
+// the first conversion
+template <int F16>
+__device__ __forceinline__ void elem_saturate() {
+  if (F16) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
+}
+template <int F16>
+__device__ __forceinline__ f32x4 elem_mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x4& c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // defined in conv1d_bf16_v2.hip: the 256x256-tile kernel for wide layers
 int conv1d_bf16_v2_launch(const ConvBArgs& a, int KW, hipStream_t stream);
 // defined in conv1d_bf16_k3.hip: the same tile for width 3, one activation slab shared by the three taps
@@ -85,9 +119,11 @@ int conv1d_bf16_k3_launch(const ConvBArgs& a, hipStream_t stream);
 int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int KW);
 int conv1d_wgrad_bf16_v2_splits(int total_rows, int C, int M, int KW, int nseg, bool with_bias);
 // dbias (optional): the bias gradient, fused into the same launch; bias_partial: >= 64 * pad64(M) floats of scratch
+// elem: 0 bf16, 1 fp16; out_scale (device scalar or null): multiplied into dw / dbias (undoes a loss scale)
 int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
                                 int total_rows, int C, int M, int KW, int w_layout, int accumulate, hipStream_t s,
-                                float* dbias = nullptr, float* bias_partial = nullptr);
+                                float* dbias = nullptr, float* bias_partial = nullptr, int elem = 0,
+                                const float* out_scale = nullptr);
 
 
 }  // namespace alvq

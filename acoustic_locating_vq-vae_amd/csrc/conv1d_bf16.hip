@@ -27,7 +27,7 @@
 
 namespace alvq {
 
-template <int KW, int OUT>
+template <int KW, int OUT, int F16 = 0>
 __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
   constexpr int PAD = (KW - 1) / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = elem_mfma16<F16>(af[mi], bfr[ni], acc[mi][ni]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -119,9 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
   }
 
   if (OUT == 0) {   // NLC bf16: straight from the accumulators (conv1d_bf16_tile256.h)
-    wave_epilogue_bf16<4, 4>(a, acc, m0, r0, li, kq, wm0, wn0);
+    wave_epilogue_bf16<4, 4, F16>(a, acc, m0, r0, li, kq, wm0, wn0);
     return;
   }
+  const float oscale = a.out_scale ? *a.out_scale : 1.f;
   // ---- OUT == 1, step 1: D[i = m][j = row] -> fp32 C tile Cs[row][m] (4 consecutive m per lane = one 16-B write)
   float* Cs = (float*)lds;
 #pragma unroll
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
       for (int ml = tid >> 7; ml < TB_M; ml += 2) {
         const int m = m0 + ml;
         if (m >= a.M) break;
-        a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * CS + ml] + (a.bias ? a.bias[m] : 0.f);
+        a.y_ncl[((long)b * a.M + m) * a.L + l] = (Cs[rl * CS + ml] + (a.bias ? a.bias[m] : 0.f)) * oscale;
       }
     }
   }
@@ -151,8 +152,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
 
 // ------------------------------------------------------------------------------------------- helpers
 // (B,C,L) fp32 -> NLC-padded bf16 [rows_total][Cp] (gap rows, tail rows and padded channels zero).
-__global__ __launch_bounds__(256) void ncl_to_nlc_kernel(const float* x, u16* y, int B, int C, int L, int Cp, int rows_total) {
+template <int F16 = 0>
+__global__ __launch_bounds__(256) void ncl_to_nlc_kernel(const float* x, u16* y, int B, int C, int L, int Cp, int rows_total,
+                                                         const float* scale = nullptr) {
   __shared__ float tile[32][33];
+  elem_saturate<F16>();
+  const float sc = scale ? *scale : 1.f;
   const int ct = Cp / 32, rt = (rows_total + 31) / 32;
   const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
   (void)rt;
@@ -163,19 +168,22 @@ __global__ __launch_bounds__(256) void ncl_to_nlc_kernel(const float* x, u16* y,
     const int c = c0 + ty + 8 * i, row = r0 + tx;
     int b, l;
     const bool ok = row_valid(row, Lp1, ndata, &b, &l) && c < C;
-    tile[ty + 8 * i][tx] = ok ? x[((long)b * C + c) * L + l] : 0.f;
+    tile[ty + 8 * i][tx] = ok ? x[((long)b * C + c) * L + l] * sc : 0.f;
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {  // write: lanes along channels
     const int row = r0 + ty + 8 * i, c = c0 + tx;
-    if (row < rows_total) y[(long)row * Cp + c] = f2bf(tile[tx][ty + 8 * i]);
+    if (row < rows_total) y[(long)row * Cp + c] = F16 ? (u16)(elem_pk<1>(tile[tx][ty + 8 * i], 0.f) & 0xffffu) : f2bf(tile[tx][ty + 8 * i]);
   }
 }
 
 // NLC-padded bf16 -> (B,C,L) fp32 (for module outputs that leave the bf16 pipeline).
-__global__ __launch_bounds__(256) void nlc_to_ncl_kernel(const u16* x, float* y, int B, int C, int L, int Cp, int rows_total) {
+template <int F16 = 0>
+__global__ __launch_bounds__(256) void nlc_to_ncl_kernel(const u16* x, float* y, int B, int C, int L, int Cp, int rows_total,
+                                                         const float* scale = nullptr) {
   __shared__ float tile[32][33];
+  const float sc = scale ? *scale : 1.f;
   const int ct = Cp / 32;
   const int r0 = (blockIdx.x / ct) * 32, c0 = (blockIdx.x % ct) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void nlc_to_ncl_kernel(const u16* x, float* y,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {  // read: lanes along channels
     const int row = r0 + ty + 8 * i, c = c0 + tx;
-    tile[ty + 8 * i][tx] = row < rows_total ? bf2f(x[(long)row * Cp + c]) : 0.f;
+    tile[ty + 8 * i][tx] = row < rows_total ? elem2f<F16>(x[(long)row * Cp + c]) * sc : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -194,13 +202,13 @@ __global__ __launch_bounds__(256) void nlc_to_ncl_kernel(const u16* x, float* y,
   }
 }
 
-// out = mask > 0 ? dy : 0 on NLC bf16 buffers (whole padded matrix)
+// out = mask > 0 ? dy : 0 on NLC bf16 or fp16 buffers (whole padded matrix): a positive bf16 / fp16 is a positive int16
 __global__ __launch_bounds__(256) void relu_mask_bf16_kernel(const u16* dy, const u16* t, u16* out, long n8) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n8; e += (long)gridDim.x * 256) {
     const u16x8 d = ((const u16x8*)dy)[e], m = ((const u16x8*)t)[e];
     u16x8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = bf2f(m[i]) > 0.f ? d[i] : (u16)0;
+    for (int i = 0; i < 8; ++i) o[i] = (short)m[i] > 0 ? d[i] : (u16)0;
     ((u16x8*)out)[e] = o;
   }
 }
@@ -229,8 +237,8 @@ extern "C" int alvq_ncl_to_nlc_bf16(const float* x, void* y, int B, int C, int L
   ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_ncl_to_nlc_bf16: null pointer");
   ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_ncl_to_nlc_bf16: bad dims");
   const int Cp = pad_to(C, TB_K), rows = (int)alvq_nlc_rows(B, L);
-  hipLaunchKernelGGL(ncl_to_nlc_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y, B, C,
-                     L, Cp, rows);
+  hipLaunchKernelGGL(ncl_to_nlc_kernel<0>, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y, B, C,
+                     L, Cp, rows, (const float*)nullptr);
   return check_launch("alvq_ncl_to_nlc_bf16");
 }
 
@@ -238,8 +246,8 @@ extern "C" int alvq_nlc_to_ncl_f32(const void* x, float* y, int B, int C, int L,
   ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_nlc_to_ncl_f32: null pointer");
   ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_nlc_to_ncl_f32: bad dims");
   const int Cp = pad_to(C, TB_K), rows = (int)alvq_nlc_rows(B, L);
-  hipLaunchKernelGGL(nlc_to_ncl_kernel, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, (const u16*)x, y, B,
-                     C, L, Cp, rows);
+  hipLaunchKernelGGL(nlc_to_ncl_kernel<0>, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, (const u16*)x, y, B,
+                     C, L, Cp, rows, (const float*)nullptr);
   return check_launch("alvq_nlc_to_ncl_f32");
 }
 
@@ -253,9 +261,10 @@ extern "C" int alvq_relu_mask_bf16(const void* dy, const void* t, void* out, int
   return check_launch("alvq_relu_mask_bf16");
 }
 
-extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
-                                const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M,
-                                int L, int KW, int relu, const void* mask_bits, void* relu_bits_out, void* stream) {
+// the 16-bit convolution behind alvq_conv1d_bf16 (elem 0) and alvq_conv1d_f16 (elem 1)
+static int conv1d_16bit(int elem, const float* out_scale, const void* x, const void* wp, const float* bias, const void* skip1,
+                        const void* skip2, const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M,
+                        int L, int KW, int relu, const void* mask_bits, void* relu_bits_out, void* stream) {
   ALVQ_REQUIRE(x && wp && (y || y_ncl), ALVQ_EINVAL, "alvq_conv1d_bf16: null x/wp/y");
   ALVQ_REQUIRE(!(y && y_ncl), ALVQ_EINVAL, "alvq_conv1d_bf16: choose one of y (NLC bf16) and y_ncl (NCL fp32)");
   ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_bf16: bad dims");
@@ -272,6 +281,8 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
   ALVQ_REQUIRE(!y_ncl || (!mask_bits && !relu_bits_out), ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16: sign bits go with the NLC output");
   hipStream_t s = (hipStream_t)stream;
   a.relu = relu ? 1 : 0;
+  a.elem = elem;
+  a.out_scale = out_scale;
   // Wide layers: 256 x 256 tiles whenever the 256-wide m-tile is (nearly) full -- the width-3 kernel with the shared
   // activation slab, or the generic one; narrow or ragged M (128, 192, 201, 64, 1) stays on 128 x 128 tiles, which
   // waste less there and give more workgroups.  ALVQ_CONV_V2=0 / ALVQ_CONV_K3=0 force the fallbacks (used by
@@ -290,9 +301,21 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<3, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }
   const dim3 grid(a.rtiles * a.mtiles), block(256);
-  if (KW == 3) {
+  if (elem) {
+    if (KW == 3) {
+      if (y) hipLaunchKernelGGL((conv1d_bf16_kernel<3, 0, 1>), grid, block, LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((conv1d_bf16_kernel<3, 1, 1>), grid, block, LDS_BYTES, s, a);
+    } else {
+      if (y) hipLaunchKernelGGL((conv1d_bf16_kernel<1, 0, 1>), grid, block, LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((conv1d_bf16_kernel<1, 1, 1>), grid, block, LDS_BYTES, s, a);
+    }
+  } else if (KW == 3) {
     if (y) hipLaunchKernelGGL((conv1d_bf16_kernel<3, 0>), grid, block, LDS_BYTES, s, a);
     else hipLaunchKernelGGL((conv1d_bf16_kernel<3, 1>), grid, block, LDS_BYTES, s, a);
   } else {
@@ -300,6 +323,39 @@ extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias
     else hipLaunchKernelGGL((conv1d_bf16_kernel<1, 1>), grid, block, LDS_BYTES, s, a);
   }
   return check_launch("alvq_conv1d_bf16");
+}
+
+extern "C" int alvq_conv1d_bf16(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
+                                const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M,
+                                int L, int KW, int relu, const void* mask_bits, void* relu_bits_out, void* stream) {
+  return conv1d_16bit(0, nullptr, x, wp, bias, skip1, skip2, mask, post, y, y2, y_ncl, B, C, M, L, KW, relu, mask_bits, relu_bits_out,
+                      stream);
+}
+
+// ---- fp16 element type (the backward pass of the f16mx_hb mode; include/alvq.h)
+extern "C" int alvq_conv1d_f16(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
+                               const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M, int L,
+                               int KW, int relu, const void* mask_bits, void* relu_bits_out, const float* out_scale, void* stream) {
+  return conv1d_16bit(1, out_scale, x, wp, bias, skip1, skip2, mask, post, y, y2, y_ncl, B, C, M, L, KW, relu, mask_bits,
+                      relu_bits_out, stream);
+}
+
+extern "C" int alvq_ncl_to_nlc_f16(const float* x, void* y, int B, int C, int L, const float* scale, void* stream) {
+  ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_ncl_to_nlc_f16: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_ncl_to_nlc_f16: bad dims");
+  const int Cp = pad_to(C, TB_K), rows = (int)alvq_nlc_rows(B, L);
+  hipLaunchKernelGGL(ncl_to_nlc_kernel<1>, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, x, (u16*)y, B, C, L, Cp,
+                     rows, scale);
+  return check_launch("alvq_ncl_to_nlc_f16");
+}
+
+extern "C" int alvq_nlc_to_ncl_f16(const void* x, float* y, int B, int C, int L, const float* scale, void* stream) {
+  ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_nlc_to_ncl_f16: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && L > 0, ALVQ_EINVAL, "alvq_nlc_to_ncl_f16: bad dims");
+  const int Cp = pad_to(C, TB_K), rows = (int)alvq_nlc_rows(B, L);
+  hipLaunchKernelGGL(nlc_to_ncl_kernel<1>, dim3((rows / 32) * (Cp / 32)), dim3(256), 0, (hipStream_t)stream, (const u16*)x, y, B, C, L,
+                     Cp, rows, scale);
+  return check_launch("alvq_nlc_to_ncl_f16");
 }
 
 // workspace = the split partials of the weight gradient, then 64 * pad64(M) floats of bias-gradient partials
@@ -325,6 +381,30 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
   // the bias gradient rides in the same launch (column sums of dY by an all-ones MFMA operand)
   return conv1d_wgrad_bf16_v2_launch(&dy, &x, 1, dw, workspace, rows, C, M, KW, w_layout, accumulate, (hipStream_t)stream,
                                      dbias, (float*)((char*)workspace + wgrad_bias_offset(rows, C, M, KW)));
+}
+
+extern "C" int alvq_conv1d_wgrad_f16(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C, int M,
+                                     int L, int KW, int w_layout, int accumulate, const float* inv_scale, void* stream) {
+  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16: null pointer");
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16: w_layout");
+  const int rows = (int)alvq_nlc_rows(B, L);
+  return conv1d_wgrad_bf16_v2_launch(&dy, &x, 1, dw, workspace, rows, C, M, KW, w_layout, accumulate, (hipStream_t)stream, dbias,
+                                     (float*)((char*)workspace + wgrad_bias_offset(rows, C, M, KW)), 1, inv_scale);
+}
+
+extern "C" int alvq_conv1d_wgrad_f16_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace, int B,
+                                           int C, int M, int L, int KW, int w_layout, int accumulate, const float* inv_scale,
+                                           void* stream) {
+  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16_multi: null pointer");
+  ALVQ_REQUIRE(nseg >= 1 && nseg <= 4, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16_multi: nseg=%d (1..4)", nseg);
+  for (int i = 0; i < nseg; ++i) ALVQ_REQUIRE(dy[i] && x[i], ALVQ_EINVAL, "alvq_conv1d_wgrad_f16_multi: null segment %d", i);
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16_multi: bad dims");
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16_multi: KW=%d (only 1 and 3)", KW);
+  ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16_multi: w_layout");
+  return conv1d_wgrad_bf16_v2_launch(dy, x, nseg, dw, workspace, (int)alvq_nlc_rows(B, L), C, M, KW, w_layout, accumulate,
+                                     (hipStream_t)stream, nullptr, nullptr, 1, inv_scale);
 }
 
 extern "C" int alvq_conv1d_wgrad_bf16_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,

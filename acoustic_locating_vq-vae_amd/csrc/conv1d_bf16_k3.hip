@@ -28,7 +28,7 @@ constexpr int K3_STAGE = 3 * V2_HALF + K3_XSLAB;          // 66560 B
 constexpr int K3_LDS = 2 * K3_STAGE;                      // 133120 B
 static_assert(V2_EPI_LDS <= K3_LDS, "C slab must fit");
 
-template <int OUT>
+template <int OUT, int F16 = 0>
 __global__ __launch_bounds__(512, 2) void conv1d_bf16_k3_kernel(ConvBArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_k3_kernel(ConvBArgs a) {
       for (int ni = 0; ni < 4; ++ni)
         // tied inline asm rather than the builtin: hipcc does not tie the builtin's destination to its C operand
         // (the accumulators then wander through the register file and this kernel spills inside the loop)
-        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(fa[mi]), "v"(fb[q][ni]));
+        if (F16) asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(fa[mi]), "v"(fb[q][ni]));
+        else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(fa[mi]), "v"(fb[q][ni]));
   };
 
   const int nch = Cp / V2_K;        // chunks; always even (Cp % 64 == 0)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_k3_kernel(ConvBArgs a) {
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   __syncthreads();   // OUT == 1: the C slab overlays the stages
 
-  tile256_epilogue<OUT>(a, acc, lds, m0, r0, wave, tid, li, kq, wm0);
+  tile256_epilogue<OUT, F16>(a, acc, lds, m0, r0, wave, tid, li, kq, wm0);
 }
 
 int conv1d_bf16_k3_launch(const ConvBArgs& a_in, hipStream_t stream) {
@@ -195,9 +196,14 @@ int conv1d_bf16_k3_launch(const ConvBArgs& a_in, hipStream_t stream) {
   if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_k3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_k3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_k3_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_k3_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS);
   }
   const dim3 grid(a.rtiles * a.mtiles), block(512);
-  if (a.y) hipLaunchKernelGGL((conv1d_bf16_k3_kernel<0>), grid, block, K3_LDS, stream, a);
+  if (a.elem) {
+    if (a.y) hipLaunchKernelGGL((conv1d_bf16_k3_kernel<0, 1>), grid, block, K3_LDS, stream, a);
+    else hipLaunchKernelGGL((conv1d_bf16_k3_kernel<1, 1>), grid, block, K3_LDS, stream, a);
+  } else if (a.y) hipLaunchKernelGGL((conv1d_bf16_k3_kernel<0>), grid, block, K3_LDS, stream, a);
   else hipLaunchKernelGGL((conv1d_bf16_k3_kernel<1>), grid, block, K3_LDS, stream, a);
   return check_launch("alvq_conv1d_bf16(k3)");
 }

@@ -31,17 +31,18 @@ struct FragSet {
 //     run along l.  All waves must have finished reading the operand stages before the call.
 // The register-direct bf16 epilogue of one wave's (NMI*16) m x (NNI*16) rows block of MFMA fragments:
 // rows r0 + wn0 .., channels m0 + wm0 ..   (NMI even: fragments are swapped in pairs)
-template <int NMI, int NNI>
+template <int NMI, int NNI, int F16 = 0>
 __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[NMI][NNI], int m0, int r0, int li,
                                                    int kq, int wm0, int wn0);
 
-template <int OUT>
+template <int OUT, int F16 = 0>
 __device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4 (&acc)[8][4], unsigned char* lds, int m0,
                                                  int r0, int wave, int tid, int li, int kq, int wm0) {
   if (OUT == 0) {
-    wave_epilogue_bf16(a, acc, m0, r0, li, kq, wm0, (wave & 3) * 64);
+    wave_epilogue_bf16<8, 4, F16>(a, acc, m0, r0, li, kq, wm0, (wave & 3) * 64);
     return;
   }
+  const float oscale = a.out_scale ? *a.out_scale : 1.f;
   // OUT == 1: NCL fp32 (bias only) -- lane = row (coalesced along l), loop over channels
   float* Cs = (float*)lds;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
@@ -62,7 +63,7 @@ __device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4
       for (int ml = tid >> 6; ml < V2_M; ml += 8) {
         const int m = m0 + ml;
         if (m >= a.M) break;
-        a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * V2_CS + ml] + (a.bias ? a.bias[m] : 0.f);
+        a.y_ncl[((long)b * a.M + m) * a.L + l] = (Cs[rl * V2_CS + ml] + (a.bias ? a.bias[m] : 0.f)) * oscale;
       }
     }
     __syncthreads();
@@ -77,10 +78,11 @@ __device__ __forceinline__ void tile256_epilogue(const ConvBArgs& a, const f32x4
 //  * gap / tail rows (one 16-row block in thirty holds one) are zeroed by a select on the four packed output words,
 //    inside a wave-uniform branch, instead of a divergent branch around the whole group;
 //  * the bias of a group that lies inside M is two 16-byte loads.
-template <int NMI, int NNI>
+template <int NMI, int NNI, int F16>
 __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32x4 (&acc)[NMI][NNI], int m0, int r0, int li,
                                                    int kq, int wm0, int wn0) {
   static_assert(NMI % 2 == 0, "fragments are swapped in pairs");
+  elem_saturate<F16>();
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   const int mb0 = m0 + wm0 + (kq & 1) * 16 + (kq >> 1) * 8;      // this lane's 8 channels of fragment pair 0
 #pragma unroll
@@ -130,11 +132,11 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
       }
       if (a.skip1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bf2f(s1[mp / 2][e]);
+        for (int e = 0; e < 8; ++e) v[e] += elem2f<F16>(s1[mp / 2][e]);
       }
       if (a.skip2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bf2f(s2[mp / 2][e]);
+        for (int e = 0; e < 8; ++e) v[e] += elem2f<F16>(s2[mp / 2][e]);
       }
       if (a.relu & 1) {
 #pragma unroll
@@ -146,11 +148,11 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
         for (int e = 0; e < 8; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (unsigned)((bt << (31 - e)) >> 31));
       } else if (a.mask) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(mk[mp / 2][e]) > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = (short)mk[mp / 2][e] > 0 ? v[e] : 0.f;   // a positive bf16 / fp16 is a positive int16
       }
       u32x4 out;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) out[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
+      for (int e = 0; e < 4; ++e) out[e] = elem_pk<F16>(v[2 * e], v[2 * e + 1]);
       if (gaps) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = ok ? out[e] : 0u;
@@ -160,14 +162,14 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
         const u16x8 ps = *(const u16x8*)(a.post + o);
         u32x4 out2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out2[e] = f2bf_pk(v[2 * e] + bf2f(ps[2 * e]), v[2 * e + 1] + bf2f(ps[2 * e + 1]));
+        for (int e = 0; e < 4; ++e) out2[e] = elem_pk<F16>(v[2 * e] + elem2f<F16>(ps[2 * e]), v[2 * e + 1] + elem2f<F16>(ps[2 * e + 1]));
         if (gaps) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) out2[e] = ok ? out2[e] : 0u;
         }
         *(u32x4*)(a.y2 + o) = out2;
       }
-      if (a.bits_out) {   // bit e = (stored y[e] > 0): a bf16 in the upper half of a word is the fp32 pattern of its value
+      if (a.bits_out) {   // bit e = (stored y[e] > 0): a bf16 / fp16 in the upper half of a word is positive iff the word is, as an int
         unsigned bt = 0;
 #pragma unroll
         for (int e = 7; e >= 0; --e) {

@@ -28,7 +28,7 @@ constexpr int V2_NSTAGE = 4;
 constexpr int V2_LDS = V2_NSTAGE * V2_STAGE;      // 131072 B
 static_assert(V2_EPI_LDS <= V2_LDS, "C slab must fit");
 
-template <int OUT>
+template <int OUT, int F16 = 0>
 __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int KW) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int PAD = (KW - 1) / 2;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
     for (int mi = half * 4; mi < half * 4 + 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = elem_mfma16<F16>(f.a[mi], f.b[ni], acc[mi][ni]);
   };
 
   const int n = (Cp / V2_K) * KW;   // K-tiles; always even (Cp % 64 == 0)
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
     __builtin_amdgcn_s_barrier();
   }
 
-  tile256_epilogue<OUT>(a, acc, lds, m0, r0, wave, tid, li, kq, wm0);
+  tile256_epilogue<OUT, F16>(a, acc, lds, m0, r0, wave, tid, li, kq, wm0);
 }
 
 int conv1d_bf16_v2_launch(const ConvBArgs& a_in, int KW, hipStream_t stream) {
@@ -165,9 +165,14 @@ int conv1d_bf16_v2_launch(const ConvBArgs& a_in, int KW, hipStream_t stream) {
   if (attr.need()) {
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_v2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_v2_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16_v2_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
   }
   const dim3 grid(a.rtiles * a.mtiles), block(512);
-  if (a.y) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0>), grid, block, V2_LDS, stream, a, KW);
+  if (a.elem) {
+    if (a.y) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0, 1>), grid, block, V2_LDS, stream, a, KW);
+    else hipLaunchKernelGGL((conv1d_bf16_v2_kernel<1, 1>), grid, block, V2_LDS, stream, a, KW);
+  } else if (a.y) hipLaunchKernelGGL((conv1d_bf16_v2_kernel<0>), grid, block, V2_LDS, stream, a, KW);
   else hipLaunchKernelGGL((conv1d_bf16_v2_kernel<1>), grid, block, V2_LDS, stream, a, KW);
   return check_launch("alvq_conv1d_bf16(v2)");
 }

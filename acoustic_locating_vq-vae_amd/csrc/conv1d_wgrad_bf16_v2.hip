@@ -58,7 +58,7 @@ __device__ __forceinline__ void lgkm_drain() {
   __builtin_amdgcn_sched_barrier(0);   // keep the consuming MFMAs behind the wait (guide 5.4 rule 18)
 }
 
-template <int KW, int NCF>
+template <int KW, int NCF, int F16 = 0>
 __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Args a) {
   constexpr int PAD = (KW - 1) / 2;
   constexpr int MT = 128, CT = 4 * NCF * 16;          // tile: 128 m x CT c
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
   f32x4 accb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const s16x8_t ones_raw = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  constexpr short ONE = F16 ? 0x3C00 : 0x3F80;        // 1.0 as fp16 / bf16
+  const s16x8_t ones_raw = {ONE, ONE, ONE, ONE, ONE, ONE, ONE, ONE};
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_raw);
   auto mm = [&](const Frags& f, int half) {
 #pragma unroll
@@ -195,11 +196,11 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
       for (int t = 0; t < KW; ++t)
 #pragma unroll
         for (int cf = 0; cf < NCF; ++cf)
-          acc[t][mi][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[mi], f.b[t][cf], acc[t][mi][cf], 0, 0, 0);
+          acc[t][mi][cf] = elem_mfma16<F16>(f.a[mi], f.b[t][cf], acc[t][mi][cf]);
     if (do_bias) {
 #pragma unroll
       for (int mi = half * 2; mi < half * 2 + 2; ++mi)
-        accb[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[mi], ones, accb[mi], 0, 0, 0);
+        accb[mi] = elem_mfma16<F16>(f.a[mi], ones, accb[mi]);
     }
   };
   auto wait_keep = [&](int tiles_in_flight) {   // leave the DMA of `tiles_in_flight` K-tiles (0..2) outstanding
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v2_kernel(WgradV2Arg
 // and there is one barrier per K-tile, after which K-tile t+1 is visible and the stage K-tile t-1 occupied is free.
 typedef __attribute__((address_space(3))) s16x4_t* v3_lds_tr_ptr;
 
-template <int KW, int NC, int MF>
+template <int KW, int NC, int MF, int F16 = 0>
 __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v3_kernel(WgradV2Args a) {
   constexpr int PAD = (KW - 1) / 2;
   constexpr int MT = 2 * MF * 32, CT = 4 * NC * 32;
@@ -393,8 +394,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_bf16_v3_kernel(WgradV2Arg
   }
 #define V3_RD_A(SET, ST, MI, KS) V3_TR16(aF[SET][MI][KS], (ST) * STAGE + (aHb ^ ((MI) << 6)) + 8 * (KS) * YRB, YRB)
 #define V3_RD_B(SET, ST, TP, CF, KS) V3_TR16(bF[SET][TP][CF][KS], (ST) * STAGE + YBYTES + (bHb[TP] ^ ((CF) << 6)) + 8 * (KS) * XRB, XRB)
-#define V3_MM(SET, MI, TP, CF, KS) \
-  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[TP][MI][CF]) : "v"(aF[SET][MI][KS]), "v"(bF[SET][TP][CF][KS]));
+#define V3_MM(SET, MI, TP, CF, KS)                                                                                              \
+  if (F16) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[TP][MI][CF]) : "v"(aF[SET][MI][KS]), "v"(bF[SET][TP][CF][KS])); \
+  else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[TP][MI][CF]) : "v"(aF[SET][MI][KS]), "v"(bF[SET][TP][CF][KS]));
 #define V3_SB __builtin_amdgcn_sched_barrier(0);
 
   f32x16 acc[KW][MF][NC];
@@ -509,11 +511,12 @@ static constexpr int wgrad_v3_lds() {
 
 // dbias[m] (+)= sum_s bias_partial[s][m], fixed order
 static __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* bp, float* dbias, int splits, int Mp, int M,
-                                                                       int accumulate) {
+                                                                       int accumulate, const float* scale) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   float s = 0.f;
   for (int k = 0; k < splits; ++k) s += bp[(long)k * Mp + m];
+  if (scale) s *= *scale;
   dbias[m] = accumulate ? dbias[m] + s : s;
 }
 
@@ -548,7 +551,7 @@ int64_t conv1d_wgrad_bf16_v2_workspace_bytes(int total_rows, int C, int M, int K
 
 int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
                                 int total_rows, int C, int M, int KW, int w_layout, int accumulate, hipStream_t s,
-                                float* dbias, float* bias_partial) {
+                                float* dbias, float* bias_partial, int elem, const float* out_scale) {
   const int ct = KW == 3 ? 128 : 256;
   const int Mp = (M + 63) / 64 * 64, Cp = (C + 63) / 64 * 64;
   WgradV2Args a{};
@@ -573,18 +576,28 @@ int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v3_kernel<3, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v3_lds<3, 1, 2>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<3, 2>());
     (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<1, 4>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v3_kernel<1, 2, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v3_lds<1, 2, 4>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v3_kernel<3, 1, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v3_lds<3, 1, 2>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<3, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<3, 2>());
+    (void)hipFuncSetAttribute((const void*)conv1d_wgrad_bf16_v2_kernel<1, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wgrad_v2_lds<1, 4>());
   }
   const int grid = a.mtiles * a.ctiles * a.splits;
+  if (elem) {
+    if (v3 && KW == 1) hipLaunchKernelGGL((conv1d_wgrad_bf16_v3_kernel<1, 2, 4, 1>), dim3(grid), dim3(512), (wgrad_v3_lds<1, 2, 4>()), s, a);
+    else if (v3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v3_kernel<3, 1, 2, 1>), dim3(grid), dim3(512), (wgrad_v3_lds<3, 1, 2>()), s, a);
+    else if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<3, 2, 1>), dim3(grid), dim3(512), (wgrad_v2_lds<3, 2>()), s, a);
+    else hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<1, 4, 1>), dim3(grid), dim3(512), (wgrad_v2_lds<1, 4>()), s, a);
+  } else
   if (v3 && KW == 1) hipLaunchKernelGGL((conv1d_wgrad_bf16_v3_kernel<1, 2, 4>), dim3(grid), dim3(512), (wgrad_v3_lds<1, 2, 4>()), s, a);
   else if (v3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v3_kernel<3, 1, 2>), dim3(grid), dim3(512), (wgrad_v3_lds<3, 1, 2>()), s, a);
   else if (KW == 3) hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<3, 2>), dim3(grid), dim3(512), (wgrad_v2_lds<3, 2>()), s, a);
   else hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<1, 4>), dim3(grid), dim3(512), (wgrad_v2_lds<1, 4>()), s, a);
   int rc = check_launch("alvq_conv1d_wgrad_bf16(v2)");
   if (rc) return rc;
-  wgrad_reduce_launch((const float*)workspace, dw, a.splits, KW, M, C, w_layout, accumulate, s);
+  wgrad_reduce_launch((const float*)workspace, dw, a.splits, KW, M, C, w_layout, accumulate, s, out_scale);
   if (dbias)
     hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bias_partial, dbias,
-                       a.splits, Mp, M, accumulate);
+                       a.splits, Mp, M, accumulate, out_scale);
   return check_launch("alvq_conv1d_wgrad_bf16(v2)/reduce");
 }
 

@@ -6,9 +6,11 @@ namespace alvq {
 
 // dw (+)= sum_s partial[s]; fixed summation order -> bitwise reproducible.
 // OIK: dw[m][c][t].   IOK: dw[c][m][KW-1-t].
+// scale (device scalar or null): multiplied into the sum before it is stored / accumulated (undoes a loss scale).
 static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int splits, int KW, int M, int C, int w_layout,
-                                    int accumulate) {
+                                    int accumulate, const float* scale) {
   const long total = (long)KW * M * C;
+  const float sc = scale ? *scale : 1.f;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     // e indexes the OUTPUT (coalesced writes); decode to (m, c, t)
     int m, c, t;
@@ -31,6 +33,7 @@ static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int 
       s = (((s + v0) + v1) + v2) + v3;
     }
     for (; k < splits; ++k) s += partial[(long)k * total + src];
+    if (scale) s *= sc;
     dw[e] = accumulate ? dw[e] + s : s;
   }
 }
@@ -43,7 +46,7 @@ static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int 
 // RB / 8 x KW 8-byte loads in flight each -- at RB = 32 (512 workgroups) the kernel ran at 2 TB/s.
 template <int RB>
 static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const float* partial, float* dw, int splits, int KW,
-                                                                      int M, int C, int accumulate) {
+                                                                      int M, int C, int accumulate, const float* scale) {
   constexpr int RI = RB / 8;           // rows per thread
   __shared__ float tile[3][RB][65];
   const int ctiles = (C + 63) / 64;
@@ -127,7 +130,8 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
     const int cc = e / run, j = e - cc * run, mr = j / KW, tt = j - mr * KW;
     if (c0 + cc >= C || m0 + mr >= M) continue;
     const long o = ((long)(c0 + cc) * M + m0) * KW + j;
-    const float v = tile[KW - 1 - tt][mr][cc];
+    float v = tile[KW - 1 - tt][mr][cc];
+    if (scale) v *= *scale;
     dw[o] = accumulate ? dw[o] + v : v;
   }
 }
@@ -157,16 +161,16 @@ static inline int wgrad_split_bound(int rows, int tiles, int maxseg) {
 }
 
 static inline void wgrad_reduce_launch(const float* partial, float* dw, int splits, int KW, int M, int C, int w_layout,
-                                       int accumulate, hipStream_t s) {
+                                       int accumulate, hipStream_t s, const float* scale = nullptr) {
   if (w_layout == ALVQ_W_IOK) {
     const int grid = ((M + 15) / 16) * ((C + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_iok_kernel<16>, dim3(grid), dim3(256), 0, s, partial, dw, splits, KW, M, C, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_iok_kernel<16>, dim3(grid), dim3(256), 0, s, partial, dw, splits, KW, M, C, accumulate, scale);
     return;
   }
   const long total = (long)KW * M * C;
   int rgrid = (int)((total + 255) / 256);
   if (rgrid > 2048) rgrid = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, partial, dw, splits, KW, M, C, w_layout, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, s, partial, dw, splits, KW, M, C, w_layout, accumulate, scale);
 }
 
 }  // namespace alvq

@@ -92,6 +92,11 @@ _SIGNATURES = {
     "alvq_conv1d_wgrad_bf16_splits": (_i32, [_i32] * 7),
     "alvq_conv1d_wgrad_bf16x3_splits": (_i32, [_i32] * 6),
     "alvq_conv1d_wgrad_f16mx_splits": (_i32, [_i32] * 6),
+    "alvq_ncl_to_nlc_f16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p]),
+    "alvq_nlc_to_ncl_f16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p]),
+    "alvq_conv1d_f16": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p] * 4),
+    "alvq_conv1d_wgrad_f16": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p, _c_void_p]),
+    "alvq_conv1d_wgrad_f16_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p, _c_void_p]),
     "alvq_onehot_to_index_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
     "alvq_indices_to_i32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
     "alvq_embedding_bag_fwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 4 + [_c_void_p] * 2),
@@ -116,6 +121,8 @@ def lib():
                 "(there is no CPU fallback for the HIP path)" % path)
         handle = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
+            if os.environ.get("ALVQ_LIB_ALLOW_MISSING") == "1" and not hasattr(handle, name):
+                continue                             # tools/ab_bits.py against an OLDER build of the library
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
@@ -556,10 +563,11 @@ def spec_rir_wiener(speech_spec, echoed_spec):
 class NLC:
     """An activation in the NLC-padded layout (see include/alvq.h): storage = guard rows + matrix + guard rows.
 
-    ``fmt``: "bf16" (one plane), "bf16x3" (hi + lo bf16 planes) or "f16mx" (fp16 H plane + fp8 Q plane; same bytes and
-    geometry as bf16x3).  ``gscale``: for a gradient in the f16mx format, the 4-float device state of its loss scale
-    ({S, 1/S, ...}, alvq_grad_scale_f32) -- inherited by everything computed from it and divided out where the chain
-    leaves the format; None for forward tensors."""
+    ``fmt``: "bf16" (one plane), "bf16x3" (hi + lo bf16 planes), "f16mx" (fp16 H plane + fp8 Q plane; same bytes and
+    geometry as bf16x3) or "f16" (one fp16 plane: the gradients of the f16mx_hb mode; an f16mx tensor serves wherever an
+    "f16" operand is expected -- its H plane is one).  ``gscale``: for a gradient in the f16mx / f16 formats, the 4-float
+    device state of its loss scale ({S, 1/S, ...}, alvq_grad_scale_f32) -- inherited by everything computed from it and
+    divided out where the chain leaves the format; None for forward tensors."""
     __slots__ = ("storage", "B", "L", "C", "Cp", "rows", "guard", "planes", "has_bits", "fmt", "gscale")
 
     def __init__(self, B, L, C, device, planes=1, fmt=None, gscale=None):
@@ -605,7 +613,7 @@ class NLC:
 
     def to_ncl(self):
         """(B,C,L) fp32 copy -- test/debug helper (torch indexing, not on the hot path)."""
-        if self.fmt == "f16mx":
+        if self.fmt in ("f16mx", "f16"):
             return nlc_to_ncl(self)
         m = self.matrix(0).float()
         if self.planes == 2:
@@ -642,10 +650,15 @@ def f16mx_range_flag(reset=True, device="cuda"):
     return int(out.item())
 
 
+def _fmt_serves(t, ref):
+    """Can ``t`` be read as an operand of ``ref``'s format?  Same format, or an f16mx tensor read through its H plane."""
+    return (t.planes, t.fmt) == (ref.planes, ref.fmt) or (ref.fmt == "f16" and t.fmt == "f16mx")
+
+
 def _nlc_ptr(t, ref, C, name):
     if t is None:
         return None
-    if not isinstance(t, NLC) or (t.B, t.L, t.C, t.planes, t.fmt) != (ref.B, ref.L, C, ref.planes, ref.fmt):
+    if not isinstance(t, NLC) or (t.B, t.L, t.C) != (ref.B, ref.L, C) or not _fmt_serves(t, ref):
         raise RuntimeError("%s: expected an NLC activation of (B=%d, L=%d, C=%d, %s)" % (name, ref.B, ref.L, C, ref.fmt))
     return t.ptr
 
@@ -655,7 +668,9 @@ def ncl_to_nlc(x, planes=1, fmt=None, gscale=None):
     scale S of ``gscale`` when given)."""
     B, C, L = x.shape
     out = NLC(B, L, C, x.device, planes, fmt, gscale)
-    if out.fmt == "f16mx":
+    if out.fmt == "f16":
+        _check(lib().alvq_ncl_to_nlc_f16(_ptr(x, name="x"), out.ptr, B, C, L, _sptr(gscale, 0), _stream()), "alvq_ncl_to_nlc_f16")
+    elif out.fmt == "f16mx":
         _check(lib().alvq_ncl_to_nlc_f16mx(_ptr(x, name="x"), out.ptr, B, C, L, _sptr(gscale, 0), _stream()), "alvq_ncl_to_nlc_f16mx")
     elif planes == 2:
         _check(lib().alvq_ncl_to_nlc_bf16x3(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16x3")
@@ -667,7 +682,9 @@ def ncl_to_nlc(x, planes=1, fmt=None, gscale=None):
 def nlc_to_ncl(a):
     """NLC bf16 -> (B,C,L) fp32 dense."""
     y = torch.empty((a.B, a.C, a.L), device=a.storage.device, dtype=torch.float32)
-    if a.fmt == "f16mx":
+    if a.fmt == "f16":
+        _check(lib().alvq_nlc_to_ncl_f16(a.ptr, _ptr(y), a.B, a.C, a.L, _sptr(a.gscale, 1), _stream()), "alvq_nlc_to_ncl_f16")
+    elif a.fmt == "f16mx":
         _check(lib().alvq_nlc_to_ncl_f16mx(a.ptr, _ptr(y), a.B, a.C, a.L, _sptr(a.gscale, 1), _stream()), "alvq_nlc_to_ncl_f16mx")
     elif a.planes == 2:
         _check(lib().alvq_nlc_to_ncl_bf16x3(a.ptr, _ptr(y), a.B, a.C, a.L, _stream()), "alvq_nlc_to_ncl_bf16x3")
@@ -729,7 +746,10 @@ def pack_weights_batch(entries, planes=1):
 
 def relu_mask_bf16(dy, t):
     out = nlc_like(dy, dy.C)
-    if dy.fmt == "f16mx":
+    if dy.fmt == "f16":                  # t: fp16, or an f16mx activation through its H plane (sign test on the int16 pattern)
+        n = dy.rows * dy.Cp
+        _check(lib().alvq_relu_mask_bf16(dy.ptr, _nlc_ptr(t, dy, dy.C, "t"), out.ptr, n, _stream()), "alvq_relu_mask_bf16")
+    elif dy.fmt == "f16mx":
         _check(lib().alvq_relu_mask_f16mx(dy.ptr, _nlc_ptr(t, dy, dy.C, "t"), out.ptr, dy.B, dy.C, dy.L, _stream()),
                "alvq_relu_mask_f16mx")
     elif dy.planes == 2:
@@ -749,7 +769,7 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     wp, (M, C, KW, wplanes) = packed
     if C != x.C:
         raise RuntimeError("conv1d_bf16: weight expects %d input channels, x has %d" % (C, x.C))
-    if wplanes != (3 if x.fmt == "f16mx" else x.planes):
+    if wplanes != (3 if x.fmt in ("f16mx", "f16") else x.planes):       # an f16 launch reads the H image of an f16mx packed weight
         raise RuntimeError("conv1d_bf16: weight packed for format %d, activation is %s" % (wplanes, x.fmt))
     split = x.planes == 2
     if bias is not None and bias.numel() != M:
@@ -763,6 +783,8 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     # same dispatch rule as alvq_conv1d_bf16: wide layers run the 256x256-tile kernel
     if x.fmt == "f16mx":
         family, fn = "conv1d_f16mx_kernel", lib().alvq_conv1d_f16mx
+    elif x.fmt == "f16":
+        family, fn = "conv1d_f16_kernel", lib().alvq_conv1d_f16
     elif split:
         family, fn = "conv1d_bf16x3_kernel", lib().alvq_conv1d_bf16x3
     else:
@@ -781,7 +803,7 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
             mask_bits, mask_ptr = mask.bits_ptr, None
         bits_out = y.bits_ptr if (y is not None and relu and USE_SIGN_BITS) else None
         extra = (mask_bits, bits_out)
-    if x.fmt == "f16mx":
+    if x.fmt in ("f16mx", "f16"):
         extra += (_sptr(x.gscale, 1) if out_ncl else None,)     # a gradient leaving the format: divide the loss scale out
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
         rc = fn(x.ptr, wp.data_ptr(), _ptr(bias, name="bias"), _nlc_ptr(skip1, x, M, "skip1"),
@@ -809,10 +831,13 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
         raise RuntimeError("conv1d_wgrad_bf16: dw_out has shape %s, expected %s" % (tuple(dw_out.shape), shape))
     if want_bias and dbias_out is None:
         dbias_out = torch.empty((M,), device=dev, dtype=torch.float32)
-    if (dy.planes, dy.fmt) != (x.planes, x.fmt):
+    if not _fmt_serves(x, dy):
         raise RuntimeError("conv1d_wgrad_bf16: dy and x differ in format")
     extra = ()
-    if x.fmt == "f16mx":
+    if dy.fmt == "f16":                  # x: fp16, or the H plane of a saved f16mx activation
+        family, fn, wsfn = "conv1d_wgrad_f16_kernel", lib().alvq_conv1d_wgrad_f16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes
+        extra = (_sptr(dy.gscale, 1),)
+    elif x.fmt == "f16mx":
         family, fn, wsfn = "conv1d_wgrad_f16mx_kernel", lib().alvq_conv1d_wgrad_f16mx, lib().alvq_conv1d_wgrad_f16mx_workspace_bytes
         extra = (_sptr(dy.gscale, 1),)
     elif x.planes == 2:
@@ -832,12 +857,12 @@ def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=F
     """dw (+)= sum_i wgrad(dy_i, x_i) in one launch (shared residual weights).  pairs: [(dy NLC, x NLC), ...] (1..4)."""
     dy0, x0 = pairs[0]
     M, C = dy0.C, x0.C
-    fx, x3 = dy0.fmt == "f16mx", dy0.fmt == "bf16x3"
+    fx, x3, h16 = dy0.fmt == "f16mx", dy0.fmt == "bf16x3", dy0.fmt == "f16"
     for dy, x in pairs:
-        if (dy.B, dy.L, dy.C, dy.fmt, x.B, x.L, x.C, x.fmt) != (dy0.B, dy0.L, M, dy0.fmt, x0.B, x0.L, C, dy0.fmt) or \
-                (dy.planes, x.planes) != ((2, 2) if (fx or x3) else (1, 1)):
+        if (dy.B, dy.L, dy.C, dy.fmt, dy.planes, x.B, x.L, x.C) != (dy0.B, dy0.L, M, dy0.fmt, dy0.planes, x0.B, x0.L, C) or \
+                not _fmt_serves(x, dy):
             raise RuntimeError("conv1d_wgrad_bf16_multi: all segments must share one shape and format")
-        if fx and dy.gscale is not dy0.gscale:
+        if (fx or h16) and dy.gscale is not dy0.gscale:
             raise RuntimeError("conv1d_wgrad_bf16_multi: the segments belong to different loss-scale chains")
     shape = (M, C, KW) if w_layout == W_OIK else (C, M, KW)
     dev = x0.storage.device
@@ -849,6 +874,13 @@ def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=F
     n = len(pairs)
     dys = (ctypes.c_void_p * n)(*[dy.ptr for dy, _ in pairs])
     xs = (ctypes.c_void_p * n)(*[x.ptr for _, x in pairs])
+    if h16:
+        ws = _workspace(lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x0.B, C, M, x0.L, KW), dev)
+        with _timed("conv1d_wgrad_f16_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):
+            rc = lib().alvq_conv1d_wgrad_f16_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws.data_ptr(), x0.B, C, M, x0.L, KW,
+                                                   w_layout, int(bool(accumulate)), _sptr(dy0.gscale, 1), _stream())
+        _check(rc, "alvq_conv1d_wgrad_f16_multi")
+        return dw_out
     if fx:
         ws = _workspace(lib().alvq_conv1d_wgrad_f16mx_workspace_bytes(x0.B, C, M, x0.L, KW), dev)
         with _timed("conv1d_wgrad_f16mx_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):

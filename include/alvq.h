@@ -334,6 +334,31 @@ int alvq_conv1d_wgrad_f16mx_multi(const void* const* dy, const void* const* x, i
 int alvq_conv1d_wgrad_f16mx_splits(int B, int C, int M, int L, int KW, int nseg);    /* as alvq_conv1d_wgrad_bf16_splits */
 
 /* ================================================================================================
+ * fp16 element type of the 16-bit pipeline: the same kernels, layouts (NLC-padded [rows][Cp], packed weights
+ * [tap][Mp][Cp], sign bits) and contracts as the "_bf16" entry points of the same name, with fp16 elements, fp16 MFMAs
+ * (v_mfma_f32_16x16x32_f16 / 32x32x16_f16) and saturating conversions.  Used by the BACKWARD pass of the "f16mx_hb" mode
+ * (f16mx forward: fp32-grade outputs; fp16 backward: gradients under the device-chosen loss scale of alvq_grad_scale_f32,
+ * products of fp16 operands with fp32 accumulation, ~5e-4 per product): an fp16 operand may be the H plane of an f16mx
+ * activation or of an f16mx packed weight (same geometry: pass the plane's pointer), a mask its sign bits.
+ *   alvq_ncl_to_nlc_f16 / alvq_nlc_to_ncl_f16   multiply by *scale (NULL = 1) while converting
+ *   alvq_conv1d_f16        y_ncl output multiplied by *out_scale (NULL = 1)
+ *   alvq_conv1d_wgrad_f16  dw / dbias multiplied by *inv_scale (NULL = 1); workspace = alvq_conv1d_wgrad_bf16_workspace_bytes
+ *   alvq_relu_mask_bf16    serves fp16 buffers unchanged (the test is "element > 0" on the int16 pattern)
+ * ============================================================================================== */
+int alvq_ncl_to_nlc_f16(const float* x, void* y, int B, int C, int L, const float* scale, void* stream);
+int alvq_nlc_to_ncl_f16(const void* x, float* y, int B, int C, int L, const float* scale, void* stream);
+int alvq_conv1d_f16(const void* x, const void* wp, const float* bias, const void* skip1, const void* skip2,
+                    const void* mask, const void* post, void* y, void* y2, float* y_ncl,
+                    int B, int C, int M, int L, int KW, int relu, const void* mask_bits, void* relu_bits_out,
+                    const float* out_scale, void* stream);
+int alvq_conv1d_wgrad_f16(const void* dy, const void* x, float* dw, float* dbias, void* workspace,
+                          int B, int C, int M, int L, int KW, int w_layout, int accumulate,
+                          const float* inv_scale, void* stream);
+int alvq_conv1d_wgrad_f16_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
+                                int B, int C, int M, int L, int KW, int w_layout, int accumulate,
+                                const float* inv_scale, void* stream);
+
+/* ================================================================================================
  * Location head: LocationModule.fc_1 = nn.Linear(L*K, M) on the flattened one-hot codes of a
  * spectrogram (vq_vae/location_model/location_model.py:10,21; scripts/train_location.py:69-77 feeds it
  * encodings.reshape(B, 201, 1024)).  On one-hot input the dense product is an embedding bag over the indices the

@@ -1,0 +1,94 @@
+"""f16mx_hb mode: f16mx forward + fp16 backward.  The forward pass must be f16mx's BIT FOR BIT (it is the same code on the
+same operands); the gradients are mixed-precision-training grade: fp16 products with fp32 accumulation under a loss scale."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from acoustic_locating_vq_vae import _ops  # noqa: E402
+from g3_cases import run  # noqa: E402
+from oracle import vqvae_oracle as O  # noqa: E402
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b)).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    yield
+    _ops.set_compute_dtype("f32")
+
+
+def _model(cfg, seed, **kw):
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    torch.manual_seed(seed)
+    m = ConvolutionalVQVAE(*cfg, **kw)
+    with torch.no_grad():
+        m._vq._embedding.weight.normal_(0, 0.7)
+    return m.cuda().train()
+
+
+@pytest.mark.parametrize("cfg,shape,kw", [((20, 48, 8, 3, 24, 0.25, 64), (3, 20, 40), dict(use_jitter=False)),
+                                          ((201, 128, 32, 2, 128, 0.25, 128), (2, 201, 96), dict()),
+                                          ((50, 1024, 8, 2, 1024, 0.25, 64), (3, 50, 130), dict(use_jitter=False))])
+def test_forward_is_f16mx_bit_for_bit_and_gradients_are_fp16_grade(cfg, shape, kw):
+    x = O.standardise(torch.randn(*shape, generator=torch.Generator().manual_seed(5)).abs()).cuda()
+    outs = {}
+    for mode in ("f16mx", "f16mx_hb", "f32"):
+        _ops.set_compute_dtype(mode)
+        m = _model(cfg, 11, **kw)
+        np.random.seed(3)
+        vq_loss, recon, perp = m(x)
+        (F.mse_loss(recon, x) + vq_loss).backward()
+        _, _, _, idx = m.get_latent_indices(x)
+        outs[mode] = (vq_loss.detach(), recon.detach(), perp.detach(), idx, {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    a, b, ref = outs["f16mx"], outs["f16mx_hb"], outs["f32"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    worst = 0.0
+    for k, g in b[4].items():
+        l2 = float((g - ref[4][k]).norm() / ref[4][k].norm())
+        worst = max(worst, l2)
+        assert l2 < 1e-2, (k, l2)                       # fp16-grade: measured ~1e-3 (f16mx: ~4e-4); never bf16's 0.1
+        assert torch.isfinite(g).all()
+    print("f16mx_hb gradient rel-L2 vs f32, worst tensor: %.2e" % worst)
+
+
+@pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
+def test_default_configs_against_reference_golden(tag, golden_dir):
+    """The north star's forward bar exactly as for f16mx (tests/test_default_configs_modes_gpu.py): indices bit-exact,
+    outputs 1e-3 (measured 2e-5), losses 1e-5; gradients at the fp16 bar."""
+    _ops.set_compute_dtype("f16mx_hb")
+    r = run(tag, golden_dir)
+    print("g3-%s f16mx_hb: %s" % (tag, json.dumps(r)))
+    if tag != "echoed":
+        assert r["idx_mismatches"] == 0, r
+        assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-5, r
+        assert r["vq_loss_rel"] < 1e-5 and r["perplexity_rel"] < 1e-5, r
+    assert r["recon_error_rel"] < 1e-5, r
+    assert r["recon_rel_max"] < 1e-3 and r["recon_sum_rel"] < 1e-5, r
+    assert r["grad_rel_max"] < 0.15 and r["grad_rel_l2_max"] < 3e-2 and r["grad_rel_l2_median"] < 1e-2, r
+
+
+def test_trainer_steps_track_the_f16mx_mode():
+    """A few Trainer steps (graph replay included) in f16mx_hb against f16mx: same first loss to the bit (same forward),
+    later losses within the gradient noise."""
+    from acoustic_locating_vq_vae.train_step import Trainer
+    cfg = (40, 128, 16, 2, 64, 0.25, 64)
+    raws = [torch.randn(4, 40, 60, generator=torch.Generator().manual_seed(10 + i)).cuda() for i in range(5)]
+    losses = {}
+    for mode in ("f16mx", "f16mx_hb"):
+        _ops.set_compute_dtype(mode)
+        m = _model(cfg, 7)
+        tr = Trainer(m, "speech")
+        np.random.seed(5)
+        tr.capture(raws[0], warmup=1)
+        losses[mode] = [float(tr.step(r)[0]) for r in raws]
+    assert np.isfinite(losses["f16mx_hb"]).all()
+    np.testing.assert_allclose(losses["f16mx_hb"], losses["f16mx"], rtol=5e-3)

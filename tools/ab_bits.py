@@ -18,8 +18,13 @@ from acoustic_locating_vq_vae import _native as N  # noqa: E402
 def digest(*tensors):
     h = hashlib.sha256()
     for t in tensors:
-        if isinstance(t, N.NLC):
-            t = t.storage
+        if isinstance(t, N.NLC):     # the defined parts only: the planes' matrices and, if valid, the sign bits (guard rows hold garbage)
+            for pl in range(t.planes):
+                h.update(t.matrix(pl).contiguous().view(torch.uint8).cpu().numpy().tobytes())
+            if t.has_bits:
+                off = (t.bits_ptr - t.storage.data_ptr())
+                h.update(t.storage.view(torch.uint8)[off:off + t.rows * t.Cp // 8].cpu().numpy().tobytes())
+            continue
         h.update(t.detach().contiguous().view(torch.uint8).cpu().numpy().tobytes())
     return h.hexdigest()[:16]
 
