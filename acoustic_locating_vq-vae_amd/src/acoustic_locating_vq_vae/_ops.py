@@ -21,11 +21,18 @@ Two precisions share these chains through a small "engine" object:
   rate); ~1.5e-5 per product, same parity class as bf16x3 at ~2/3 of its matrix time.  Gradients run under a
   power-of-two loss scale chosen on the device (csrc/f16mx_common.h).
 
-Select with ``set_compute_dtype("f32" | "bf16" | "bf16x3" | "f16mx")`` or the environment variable ``ALVQ_DTYPE``.
-DEFAULT (round 3): ``f16mx`` -- the fastest mode that holds the reference's forward results (codebook indices bit-exact,
-outputs within 2e-5 on the default-config goldens), so that ``scripts/train_speech.py`` unchanged runs at ~5x the
-``f32`` mode's rate.  ``ALVQ_DTYPE=f32`` selects the exact-fp32 MFMA mode (strict gradient parity, 1e-6).  f16mx carries
-fp16's range: activations must stay below 65504 (``_native.f16mx_range_flag()`` reports inputs that do not).
+* ``f16mx_hb`` -- f16mx forward + fp16 ("half") backward: the forward is f16mx's bit for bit; every backward product is
+  one fp16 MFMA on the H planes of the saved activations / packed weights and of gradients kept as ONE fp16 plane under the
+  loss scale.  Measured against f32 at the speech config (tools/gate_flips.py): gradient rel-L2 4.8e-4 median (f16mx:
+  4.3e-4) -- in both modes the gradient error is set by the ~1e-5 forward noise flipping ReLU gates, not by the backward
+  products -- at 0.72x the f16mx step time.
+
+Select with ``set_compute_dtype(...)`` or the environment variable ``ALVQ_DTYPE``.
+DEFAULT (round 3): ``f16mx_hb`` -- the fastest mode that holds the reference's forward results (codebook indices
+bit-exact, outputs within 2e-5 on the default-config goldens), so that ``scripts/train_speech.py`` unchanged runs at ~7x
+the ``f32`` mode's rate.  ``ALVQ_DTYPE=f16mx`` keeps the cross terms in the backward pass too; ``ALVQ_DTYPE=f32`` selects
+the exact-fp32 MFMA mode (strict gradient parity, 1e-6).  The f16mx modes carry fp16's range: activations must stay below
+65504 (``_native.f16mx_range_flag()`` reports inputs that do not).
 """
 from __future__ import annotations
 
@@ -38,7 +45,7 @@ from . import _native as N
 
 OIK, IOK = N.W_OIK, N.W_IOK
 
-DEFAULT_DTYPE = "f16mx"
+DEFAULT_DTYPE = "f16mx_hb"
 _DTYPE = os.environ.get("ALVQ_DTYPE", DEFAULT_DTYPE)
 if _DTYPE not in ("f32", "bf16", "bf16x3", "f16mx", "f16mx_hb"):
     raise ValueError("ALVQ_DTYPE must be 'f32', 'bf16', 'bf16x3', 'f16mx' or 'f16mx_hb', got %r" % (_DTYPE,))

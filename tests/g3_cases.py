@@ -165,7 +165,7 @@ def run(tag, golden_dir=GOLDEN):
 if __name__ == "__main__":      # python tests/g3_cases.py [modes...]  -> one JSON line per (mode, config)
     import json
     from acoustic_locating_vq_vae import _ops
-    for mode in (sys.argv[1:] or ["f32", "bf16x3", "f16mx", "bf16"]):
+    for mode in (sys.argv[1:] or ["f32", "bf16x3", "f16mx", "f16mx_hb", "bf16"]):
         _ops.set_compute_dtype(mode)
         for tag in ("speech", "rir", "echoed"):
             print(json.dumps({"mode": mode, **run(tag)}), flush=True)

@@ -40,7 +40,7 @@ def test_bf16_default_configs_against_reference_golden(mode, tag, golden_dir):
 
 
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
-@pytest.mark.parametrize("mode", ["bf16x3", "f16mx"], indirect=True)
+@pytest.mark.parametrize("mode", ["bf16x3", "f16mx", "f16mx_hb"], indirect=True)
 def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_dir):
     """The north star's bar, unconditionally: codebook indices BIT-EXACT (0 of 1000 / 402 differ -- the goldens' smallest
     relative top-2 gap is 3e-5, so there is no near-tie to excuse), outputs within 1e-3 (measured 2e-5) on 4096-element
