@@ -3,7 +3,7 @@
 #   tools/profile_bench.sh <dtype> [extra bench.py flags]
 # Three separate passes, as MI355X_MICROARCH.md prescribes: kernel trace + stats, then one --pmc pass per counter.
 set -e
-DT=${1:-f16mx}; shift || true
+DT=${1:-f16mx_hb}; shift || true
 R=$PWD
 OUT=$R/gpurun_out/prof_$DT
 mkdir -p $OUT
