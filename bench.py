@@ -53,7 +53,7 @@ PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF
 FAMILY_PEAK = {"conv1d_f32_kernel": ("f32", F32_MFMA_PEAK_TFLOPS), "conv1d_wgrad_f32_kernel": ("f32", F32_MFMA_PEAK_TFLOPS),
                "conv1d_bf16x3_kernel": ("bf16x3", BF16_MFMA_PEAK_TFLOPS / 3.0), "conv1d_wgrad_bf16x3_kernel": ("bf16x3", BF16_MFMA_PEAK_TFLOPS / 3.0),
                "conv1d_f16mx_kernel": ("f16mx", BF16_MFMA_PEAK_TFLOPS / 2.0), "conv1d_wgrad_f16mx_kernel": ("f16mx", BF16_MFMA_PEAK_TFLOPS / 2.0)}
-PEAK_NOTE = {"f32": "exact-fp32 MFMA peak 157.3 TFLOP/s", "bf16": "dense bf16 MFMA peak 2500 TFLOP/s",
+PEAK_NOTE = {"f32": "exact-fp32 MFMA peak 157.3 TFLOP/s", "bf16": "dense bf16 (= fp16) MFMA peak 2500 TFLOP/s",
              "bf16x3": "2500/3 = 833.3 TFLOP/s algorithmic: three bf16 MFMAs per product",
              "f16mx": "2500/2 = 1250 TFLOP/s algorithmic: one fp16 MFMA + one block-scaled fp8 MFMA of equal duration per product",
              "f16mx_hb": "whole step 1875 TFLOP/s = 1 / ((1/3)/1250 + (2/3)/2500): f16mx forward, one fp16 MFMA per backward product"}

@@ -1,4 +1,4 @@
-"""Loss curves of the four arithmetic modes over a few hundred train steps of the speech config (same initial weights,
+"""Loss curves of the arithmetic modes over a few hundred train steps of the speech config (same initial weights,
 same synthetic batches, jitter off so that the modes see identical inputs): do the split modes track fp32 beyond the
 handful of steps the parity tests cover?   python tools/long_run_modes.py [steps] [batch]"""
 import os
@@ -21,7 +21,8 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     pool = [torch.randn(B, 201, 500, device="cuda", generator=g).abs() * (1 + i % 3) for i in range(8)]
     curves = {}
-    for mode in ("f32", "f16mx", "bf16x3", "bf16"):
+    modes = ("f32", "f16mx", "f16mx_hb", "bf16x3", "bf16")
+    for mode in modes:
         _ops.set_compute_dtype(mode)
         torch.manual_seed(3)
         m = ConvolutionalVQVAE(*cfg, use_jitter=False).cuda().train()
@@ -35,10 +36,13 @@ def main():
         print(mode, " ".join("%d:%.4f" % (a, b) for a, b, _, _ in out[:: max(1, len(out) // 8)]), flush=True)
     _ops.set_compute_dtype("f32")
     ref = curves["f32"]
-    for mode in ("f16mx", "bf16x3", "bf16"):
+    for mode in modes[1:]:
         worst = max(abs(a[1] - b[1]) / abs(b[1]) for a, b in zip(curves[mode], ref))
         wp = max(abs(a[3] - b[3]) / abs(b[3]) for a, b in zip(curves[mode], ref))
-        print("%s vs f32: max relative loss deviation %.3e, perplexity %.3e over %d steps" % (mode, worst, wp, steps))
+        # how long does the mode stay within 1e-3 of the fp32 loss curve?
+        within = next((a[0] for a, b in zip(curves[mode], ref) if abs(a[1] - b[1]) > 1e-3 * abs(b[1])), steps + 1)
+        print("%s vs f32: max relative loss deviation %.3e, perplexity %.3e over %d steps; within 1e-3 of the fp32 loss up to step %d"
+              % (mode, worst, wp, steps, within - 1))
 
 
 if __name__ == "__main__":
