@@ -366,6 +366,11 @@ extern "C" int64_t alvq_conv1d_wgrad_bf16_workspace_bytes(int B, int C, int M, i
   return wgrad_bias_offset((int)alvq_nlc_rows(B, L), C, M, KW) + (int64_t)64 * pad_to(M, TB_K) * 4;
 }
 
+extern "C" int64_t alvq_conv1d_wgrad_bf16_bias_offset(int B, int C, int M, int L, int KW) {
+  if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3)) return -1;
+  return wgrad_bias_offset((int)alvq_nlc_rows(B, L), C, M, KW);
+}
+
 extern "C" int alvq_conv1d_wgrad_bf16_splits(int B, int C, int M, int L, int KW, int nseg, int with_bias) {
   if (B <= 0 || C <= 0 || M <= 0 || L <= 0 || (KW != 1 && KW != 3) || nseg < 1 || nseg > 4) return -1;
   return conv1d_wgrad_bf16_v2_splits((int)alvq_nlc_rows(B, L), C, M, KW, nseg, with_bias != 0);
@@ -373,7 +378,7 @@ extern "C" int alvq_conv1d_wgrad_bf16_splits(int B, int C, int M, int L, int KW,
 
 extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C,
                                       int M, int L, int KW, int w_layout, int accumulate, void* stream) {
-  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16: null pointer");
+  ALVQ_REQUIRE(dy && x && (dw || accumulate == ALVQ_WGRAD_DEFER) && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16: null pointer");
   ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16: bad dims");
   ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16: KW=%d (only 1 and 3)", KW);
   ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16: w_layout");
@@ -385,7 +390,7 @@ extern "C" int alvq_conv1d_wgrad_bf16(const void* dy, const void* x, float* dw, 
 
 extern "C" int alvq_conv1d_wgrad_f16(const void* dy, const void* x, float* dw, float* dbias, void* workspace, int B, int C, int M,
                                      int L, int KW, int w_layout, int accumulate, const float* inv_scale, void* stream) {
-  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16: null pointer");
+  ALVQ_REQUIRE(dy && x && (dw || accumulate == ALVQ_WGRAD_DEFER) && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16: null pointer");
   ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16: bad dims");
   ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16: KW=%d (only 1 and 3)", KW);
   ALVQ_REQUIRE(w_layout == ALVQ_W_OIK || w_layout == ALVQ_W_IOK, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16: w_layout");
@@ -397,7 +402,7 @@ extern "C" int alvq_conv1d_wgrad_f16(const void* dy, const void* x, float* dw, f
 extern "C" int alvq_conv1d_wgrad_f16_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace, int B,
                                            int C, int M, int L, int KW, int w_layout, int accumulate, const float* inv_scale,
                                            void* stream) {
-  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16_multi: null pointer");
+  ALVQ_REQUIRE(dy && x && (dw || accumulate == ALVQ_WGRAD_DEFER) && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16_multi: null pointer");
   ALVQ_REQUIRE(nseg >= 1 && nseg <= 4, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_f16_multi: nseg=%d (1..4)", nseg);
   for (int i = 0; i < nseg; ++i) ALVQ_REQUIRE(dy[i] && x[i], ALVQ_EINVAL, "alvq_conv1d_wgrad_f16_multi: null segment %d", i);
   ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_f16_multi: bad dims");
@@ -409,7 +414,7 @@ extern "C" int alvq_conv1d_wgrad_f16_multi(const void* const* dy, const void* co
 
 extern "C" int alvq_conv1d_wgrad_bf16_multi(const void* const* dy, const void* const* x, int nseg, float* dw, void* workspace,
                                             int B, int C, int M, int L, int KW, int w_layout, int accumulate, void* stream) {
-  ALVQ_REQUIRE(dy && x && dw && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16_multi: null pointer");
+  ALVQ_REQUIRE(dy && x && (dw || accumulate == ALVQ_WGRAD_DEFER) && workspace, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16_multi: null pointer");
   ALVQ_REQUIRE(nseg >= 1 && nseg <= 4, ALVQ_EUNSUPPORTED, "alvq_conv1d_wgrad_bf16_multi: nseg=%d (1..4)", nseg);
   for (int i = 0; i < nseg; ++i) ALVQ_REQUIRE(dy[i] && x[i], ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16_multi: null segment %d", i);
   ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_wgrad_bf16_multi: bad dims");

@@ -594,6 +594,7 @@ int conv1d_wgrad_bf16_v2_launch(const void* const* dy, const void* const* x, int
   else hipLaunchKernelGGL((conv1d_wgrad_bf16_v2_kernel<1, 4>), dim3(grid), dim3(512), (wgrad_v2_lds<1, 4>()), s, a);
   int rc = check_launch("alvq_conv1d_wgrad_bf16(v2)");
   if (rc) return rc;
+  if (accumulate == ALVQ_WGRAD_DEFER) return ALVQ_OK;   // the caller sums the partials later (alvq_wgrad_reduce_batch)
   wgrad_reduce_launch((const float*)workspace, dw, a.splits, KW, M, C, w_layout, accumulate, s, out_scale);
   if (dbias)
     hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)bias_partial, dbias,

@@ -7,11 +7,14 @@ namespace alvq {
 // dw (+)= sum_s partial[s]; fixed summation order -> bitwise reproducible.
 // OIK: dw[m][c][t].   IOK: dw[c][m][KW-1-t].
 // scale (device scalar or null): multiplied into the sum before it is stored / accumulated (undoes a loss scale).
-static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int splits, int KW, int M, int C, int w_layout,
-                                    int accumulate, const float* scale) {
+// Body shared by the single launch and the batched one (wgrad_reduce_batch.hip): block `bid` of `nblk` 256-thread blocks.
+// `stride`: elements between consecutive partials (KW * M * C unless the partials are padded, e.g. bias sums [splits][Mp]).
+static __device__ __forceinline__ void wgrad_reduce_body(const float* partial, float* dw, int splits, int KW, int M, int C,
+                                                         int w_layout, int accumulate, const float* scale, long stride, int bid,
+                                                         int nblk) {
   const long total = (long)KW * M * C;
   const float sc = scale ? *scale : 1.f;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+  for (long e = bid * 256L + threadIdx.x; e < total; e += (long)nblk * 256) {
     // e indexes the OUTPUT (coalesced writes); decode to (m, c, t)
     int m, c, t;
     if (w_layout == ALVQ_W_OIK) {
@@ -28,14 +31,18 @@ static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int 
     float s = 0.f;
     int k = 0;
     for (; k + 4 <= splits; k += 4) {    // four loads in flight; same summation order as one at a time
-      const float v0 = partial[(long)k * total + src], v1 = partial[(long)(k + 1) * total + src],
-                  v2 = partial[(long)(k + 2) * total + src], v3 = partial[(long)(k + 3) * total + src];
+      const float v0 = partial[(long)k * stride + src], v1 = partial[(long)(k + 1) * stride + src],
+                  v2 = partial[(long)(k + 2) * stride + src], v3 = partial[(long)(k + 3) * stride + src];
       s = (((s + v0) + v1) + v2) + v3;
     }
-    for (; k < splits; ++k) s += partial[(long)k * total + src];
+    for (; k < splits; ++k) s += partial[(long)k * stride + src];
     if (scale) s *= sc;
     dw[e] = accumulate ? dw[e] + s : s;
   }
+}
+static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int splits, int KW, int M, int C, int w_layout,
+                                    int accumulate, const float* scale) {
+  wgrad_reduce_body(partial, dw, splits, KW, M, C, w_layout, accumulate, scale, (long)KW * M * C, blockIdx.x, gridDim.x);
 }
 
 // IOK output (ConvTranspose1d weights): the loop above would read the partials with a stride of C floats between
@@ -45,12 +52,11 @@ static __global__ void wgrad_reduce_kernel(const float* partial, float* dw, int 
 // RB rows (m) x 64 columns (c) per workgroup; RB = 16 gives a 1024 x 1024 weight 1024 workgroups of 256 threads with
 // RB / 8 x KW 8-byte loads in flight each -- at RB = 32 (512 workgroups) the kernel ran at 2 TB/s.
 template <int RB>
-static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const float* partial, float* dw, int splits, int KW,
-                                                                      int M, int C, int accumulate, const float* scale) {
+static __device__ __forceinline__ void wgrad_reduce_iok_body(float (&tile)[3][RB][65], const float* partial, float* dw, int splits,
+                                                             int KW, int M, int C, int accumulate, const float* scale, int bid) {
   constexpr int RI = RB / 8;           // rows per thread
-  __shared__ float tile[3][RB][65];
   const int ctiles = (C + 63) / 64;
-  const int m0 = (blockIdx.x / ctiles) * RB, c0 = (blockIdx.x % ctiles) * 64;
+  const int m0 = (bid / ctiles) * RB, c0 = (bid % ctiles) * 64;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const long plane = (long)M * C, total = (long)KW * plane;
   const bool pair = (C % 2 == 0);          // 8-byte loads need an even row stride
@@ -134,6 +140,12 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const floa
     if (scale) v *= *scale;
     dw[o] = accumulate ? dw[o] + v : v;
   }
+}
+template <int RB>
+static __global__ __launch_bounds__(256) void wgrad_reduce_iok_kernel(const float* partial, float* dw, int splits, int KW,
+                                                                      int M, int C, int accumulate, const float* scale) {
+  __shared__ float tile[3][RB][65];
+  wgrad_reduce_iok_body<RB>(tile, partial, dw, splits, KW, M, C, accumulate, scale, blockIdx.x);
 }
 
 // Split plan of the NLC weight-gradient kernels (bf16, bf16x3, f16mx): the contraction runs over `total_rows` (a multiple

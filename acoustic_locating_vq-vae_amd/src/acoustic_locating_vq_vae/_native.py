@@ -97,6 +97,8 @@ _SIGNATURES = {
     "alvq_conv1d_f16": (_i32, [_c_void_p] * 10 + [_i32] * 6 + [_c_void_p] * 4),
     "alvq_conv1d_wgrad_f16": (_i32, [_c_void_p] * 5 + [_i32] * 7 + [_c_void_p, _c_void_p]),
     "alvq_conv1d_wgrad_f16_multi": (_i32, [_c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p] + [_i32] * 7 + [_c_void_p, _c_void_p]),
+    "alvq_conv1d_wgrad_bf16_bias_offset": (_i64, [_i32] * 5),
+    "alvq_wgrad_reduce_batch": (_i32, [_c_void_p, _i32, _c_void_p]),
     "alvq_onehot_to_index_f32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
     "alvq_indices_to_i32": (_i32, [_c_void_p] * 3 + [_i64, _i32, _c_void_p]),
     "alvq_embedding_bag_fwd_f32": (_i32, [_c_void_p] * 4 + [_i32] * 4 + [_c_void_p] * 2),
@@ -262,6 +264,78 @@ def _workspace(nbytes, device):
         buf = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
         _WS[key] = buf
     return buf
+
+
+# ---- deferred split reductions (alvq_wgrad_reduce_batch): every deferred launch needs scratch of its own until the batch
+# launch at the end of the backward pass has summed it.  The arena is a bump allocator over grow-only buffers per
+# (device, stream) -- reset at the start of a step, never released (a captured graph keeps the raw pointers).
+WGRAD_DEFER = 2
+_ARENA = {}
+
+
+class ReduceDesc(ctypes.Structure):
+    """struct alvq_reduce_desc (include/alvq.h)"""
+    _fields_ = [("partial", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("splits", ctypes.c_int32),
+                ("KW", ctypes.c_int32), ("M", ctypes.c_int32), ("C", ctypes.c_int32), ("w_layout", ctypes.c_int32),
+                ("accumulate", ctypes.c_int32), ("stride", ctypes.c_int64)]
+
+
+def arena_reset(device):
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    st = _ARENA.get(key)
+    if st is not None:
+        st["chunk"], st["off"] = 0, 0
+
+
+def arena_alloc(nbytes, device):
+    """256-byte aligned scratch that stays valid until the next ``arena_reset`` of this (device, stream)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    st = _ARENA.setdefault(key, {"chunks": [], "chunk": 0, "off": 0})
+    nbytes = (nbytes + 255) // 256 * 256
+    while True:
+        if st["chunk"] >= len(st["chunks"]):
+            st["chunks"].append(torch.empty(max(nbytes, 256 << 20), device=device, dtype=torch.uint8))
+            st["off"] = 0
+        buf = st["chunks"][st["chunk"]]
+        if st["off"] + nbytes <= buf.numel():
+            ptr = buf.data_ptr() + st["off"]
+            st["off"] += nbytes
+            return ptr
+        st["chunk"] += 1
+        st["off"] = 0
+
+
+class DeferredReductions(list):
+    """The descriptors of a backward pass's deferred reductions, plus the tensors their raw pointers refer to that nobody
+    else keeps alive until the batch launch -- the loss-scale state of a gradient chain is freed with the chain's last
+    tensor, and the next chain's state would be allocated (and written) at the same address before the reduction ran."""
+
+    def __init__(self):
+        super().__init__()
+        self.keep = []
+
+
+def wgrad_reduce_batch(descs):
+    """descs: list of ReduceDesc -- one launch sums them all (dst (+)= scale * sum_s partial[s], split order)."""
+    if not descs:
+        return
+    arr = (ReduceDesc * len(descs))(*descs)
+    _check(lib().alvq_wgrad_reduce_batch(ctypes.addressof(arr), len(descs), _stream()), "alvq_wgrad_reduce_batch")
+    if isinstance(descs, DeferredReductions):
+        descs.keep.clear()       # the launch is queued: stream order protects the memory from here on
+
+
+def _defer_descs(defer, ws_ptr, dw, dbias, scale, nseg, B, C, M, L, KW, w_layout):
+    """``scale``: the 4-float loss-scale state of the gradient chain (its 1/S is read by the reduction), or None."""
+    L_ = lib()
+    scale_ptr = _sptr(scale, 1)
+    if scale is not None and hasattr(defer, "keep"):
+        defer.keep.append(scale)
+    splits = L_.alvq_conv1d_wgrad_bf16_splits(B, C, M, L, KW, nseg, int(dbias is not None))
+    defer.append(ReduceDesc(ws_ptr, dw.data_ptr(), scale_ptr, splits, KW, M, C, w_layout, 1, KW * M * C))
+    if dbias is not None:
+        off = L_.alvq_conv1d_wgrad_bf16_bias_offset(B, C, M, L, KW)
+        defer.append(ReduceDesc(ws_ptr + off, dbias.data_ptr(), scale_ptr, splits, 1, 1, M, W_OIK, 1, (M + 63) // 64 * 64))
 
 
 def conv1d_wgrad(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, dbias_out=None, accumulate=False):
@@ -819,8 +893,10 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     return (y, y2) if post is not None else y
 
 
-def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, dbias_out=None, accumulate=False):
-    """dy, x: NLC.  fp32 dw in the weight's native layout (and dbias)."""
+def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, dbias_out=None, accumulate=False, defer=None):
+    """dy, x: NLC.  fp32 dw in the weight's native layout (and dbias).  ``defer`` (a list; bf16 / fp16 formats, with
+    ``accumulate`` into caller-owned dw_out / dbias_out): launch the contraction only and append the reduction's descriptors
+    -- the caller sums them all later with ``wgrad_reduce_batch``."""
     M, C = dy.C, x.C
     shape = (M, C, KW) if w_layout == W_OIK else (C, M, KW)
     dev = x.storage.device
@@ -844,16 +920,21 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
         family, fn, wsfn = "conv1d_wgrad_bf16x3_kernel", lib().alvq_conv1d_wgrad_bf16x3, lib().alvq_conv1d_wgrad_bf16x3_workspace_bytes
     else:
         family, fn, wsfn = "conv1d_wgrad_bf16_v2_kernel", lib().alvq_conv1d_wgrad_bf16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes
-    ws = _workspace(wsfn(x.B, C, M, x.L, KW), dev)
+    deferred = defer is not None and accumulate and dy.fmt in ("bf16", "f16")
+    ws_ptr = arena_alloc(wsfn(x.B, C, M, x.L, KW), dev) if deferred else _workspace(wsfn(x.B, C, M, x.L, KW), dev).data_ptr()
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
         rc = fn(dy.ptr, x.ptr, _ptr(dw_out, name="dw"),
-                                          _ptr(dbias_out, name="dbias") if want_bias else None, ws.data_ptr(),
-                                          x.B, C, M, x.L, KW, w_layout, int(bool(accumulate)), *extra, _stream())
+                                          _ptr(dbias_out, name="dbias") if want_bias else None, ws_ptr,
+                                          x.B, C, M, x.L, KW, w_layout, WGRAD_DEFER if deferred else int(bool(accumulate)), *extra,
+                                          _stream())
     _check(rc, "alvq_conv1d_wgrad_bf16")
+    if deferred:
+        _defer_descs(defer, ws_ptr, dw_out, dbias_out if want_bias else None, dy.gscale if dy.fmt == "f16" else None, 1, x.B, C, M,
+                     x.L, KW, w_layout)
     return (dw_out, dbias_out) if want_bias else dw_out
 
 
-def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=False):
+def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=False, defer=None):
     """dw (+)= sum_i wgrad(dy_i, x_i) in one launch (shared residual weights).  pairs: [(dy NLC, x NLC), ...] (1..4)."""
     dy0, x0 = pairs[0]
     M, C = dy0.C, x0.C
@@ -874,12 +955,18 @@ def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=F
     n = len(pairs)
     dys = (ctypes.c_void_p * n)(*[dy.ptr for dy, _ in pairs])
     xs = (ctypes.c_void_p * n)(*[x.ptr for _, x in pairs])
+    deferred = defer is not None and accumulate and dy0.fmt in ("bf16", "f16")
+    if deferred or h16 or not (fx or x3):
+        nbytes = lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x0.B, C, M, x0.L, KW)
+        ws_ptr = arena_alloc(nbytes, dev) if deferred else _workspace(nbytes, dev).data_ptr()
+        acc = WGRAD_DEFER if deferred else int(bool(accumulate))
     if h16:
-        ws = _workspace(lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x0.B, C, M, x0.L, KW), dev)
         with _timed("conv1d_wgrad_f16_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):
-            rc = lib().alvq_conv1d_wgrad_f16_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws.data_ptr(), x0.B, C, M, x0.L, KW,
-                                                   w_layout, int(bool(accumulate)), _sptr(dy0.gscale, 1), _stream())
+            rc = lib().alvq_conv1d_wgrad_f16_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws_ptr, x0.B, C, M, x0.L, KW,
+                                                   w_layout, acc, _sptr(dy0.gscale, 1), _stream())
         _check(rc, "alvq_conv1d_wgrad_f16_multi")
+        if deferred:
+            _defer_descs(defer, ws_ptr, dw_out, None, dy0.gscale, n, x0.B, C, M, x0.L, KW, w_layout)
         return dw_out
     if fx:
         ws = _workspace(lib().alvq_conv1d_wgrad_f16mx_workspace_bytes(x0.B, C, M, x0.L, KW), dev)
@@ -895,9 +982,10 @@ def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=F
                                                       w_layout, int(bool(accumulate)), _stream())
         _check(rc, "alvq_conv1d_wgrad_bf16x3_multi")
         return dw_out
-    ws = _workspace(lib().alvq_conv1d_wgrad_bf16_workspace_bytes(x0.B, C, M, x0.L, KW), dev)
     with _timed("conv1d_wgrad_bf16_v2_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):
-        rc = lib().alvq_conv1d_wgrad_bf16_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws.data_ptr(), x0.B, C, M, x0.L, KW,
-                                                w_layout, int(bool(accumulate)), _stream())
+        rc = lib().alvq_conv1d_wgrad_bf16_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws_ptr, x0.B, C, M, x0.L, KW,
+                                                w_layout, acc, _stream())
     _check(rc, "alvq_conv1d_wgrad_bf16_multi")
+    if deferred:
+        _defer_descs(defer, ws_ptr, dw_out, None, None, n, x0.B, C, M, x0.L, KW, w_layout)
     return dw_out

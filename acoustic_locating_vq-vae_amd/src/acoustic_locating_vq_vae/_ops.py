@@ -96,6 +96,23 @@ class use_grad_sinks:
         _SINKS_ACTIVE -= 1
 
 
+# deferred split reductions: inside ``with deferred_reduce() as descs:`` (a Trainer step's backward) the weight-gradient
+# launches that accumulate into a gradient sink leave their partials in arena scratch and append descriptors; the trainer
+# sums them all with ONE launch when the backward has been queued (_native.wgrad_reduce_batch).
+_DEFERRED = None
+
+
+class deferred_reduce:
+    def __enter__(self):
+        global _DEFERRED
+        self.prev, _DEFERRED = _DEFERRED, (N.DeferredReductions() if os.environ.get("ALVQ_DEFER_REDUCE", "1") != "0" else None)
+        return _DEFERRED
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        _DEFERRED = self.prev
+
+
 def _sink(t):
     if t is None or not _SINKS_ACTIVE or not len(_GRAD_SINKS) or not t.requires_grad:
         return None
@@ -261,7 +278,10 @@ def _wgrad(eng, dy, x, kw, layout, w, b=None, dw_prev=None):
         raise RuntimeError("a convolution with a frozen weight and a trainable bias is not supported on the HIP path")
     sw, sb = _sink(w), _sink(b)
     if sw is not None and (b is None or sb is not None):
-        eng.wgrad(dy, x, kw, layout, want_bias=b is not None, dw_out=sw, dbias_out=sb, accumulate=True)
+        if _DEFERRED is not None and getattr(eng, "can_defer", False):
+            eng.wgrad(dy, x, kw, layout, want_bias=b is not None, dw_out=sw, dbias_out=sb, accumulate=True, defer=_DEFERRED)
+        else:
+            eng.wgrad(dy, x, kw, layout, want_bias=b is not None, dw_out=sw, dbias_out=sb, accumulate=True)
         return None, None
     if b is not None:
         dw, db = eng.wgrad(dy, x, kw, layout, want_bias=True, dw_out=dw_prev, accumulate=dw_prev is not None)
@@ -343,9 +363,11 @@ class _BF16Engine:
     def conv(self, x, w, layout=OIK, bias=None, skip1=None, skip2=None, mask=None, post=None, relu=False, out_f32=False):
         return N.conv1d_bf16(x, self._w(w, layout), bias, skip1, skip2, mask, post, relu, out_ncl=out_f32)
 
-    def wgrad(self, dy, x, kw, layout, want_bias=False, dw_out=None, dbias_out=None, accumulate=False):
+    can_defer = True     # the launch defers only for the bf16 / fp16 operand formats; the others reduce at once
+
+    def wgrad(self, dy, x, kw, layout, want_bias=False, dw_out=None, dbias_out=None, accumulate=False, defer=None):
         return N.conv1d_wgrad_bf16(dy, x, kw, layout, want_bias=want_bias, dw_out=dw_out, dbias_out=dbias_out,
-                                   accumulate=accumulate)
+                                   accumulate=accumulate, defer=defer)
 
     def relu_mask(self, dy, t):
         return N.relu_mask_bf16(dy, t)
@@ -470,8 +492,10 @@ def _stack_backward(eng, dh, ts, us, w1, w2, R, outer=None):
         dh = eng.conv(du, w1, IOK, skip1=dh, skip2=outer if r == 0 else None, mask=ts[r])
     if fused:
         s1, s2 = _sink(w1), _sink(w2)
-        dw2 = eng.wgrad_multi(pairs2, 1, OIK, dw_out=s2, accumulate=s2 is not None)
-        dw1 = eng.wgrad_multi(pairs1, 3, OIK, dw_out=s1, accumulate=s1 is not None)
+        d2 = {"defer": _DEFERRED} if (_DEFERRED is not None and s2 is not None and getattr(eng, "can_defer", False)) else {}
+        d1 = {"defer": _DEFERRED} if (_DEFERRED is not None and s1 is not None and getattr(eng, "can_defer", False)) else {}
+        dw2 = eng.wgrad_multi(pairs2, 1, OIK, dw_out=s2, accumulate=s2 is not None, **d2)
+        dw1 = eng.wgrad_multi(pairs1, 3, OIK, dw_out=s1, accumulate=s1 is not None, **d1)
         dw1, dw2 = (None if s1 is not None else dw1), (None if s2 is not None else dw2)
     return dh, dw1, dw2
 

@@ -288,7 +288,11 @@ class Trainer:
         backward when the model has a single bucket).  ``_body`` and ``_body_late`` are the launch-bound part of a
         step (~130 launches) that hipGraphs capture; the collectives and the optimiser launch stay outside so no
         RCCL call is ever recorded into a graph."""
-        with _ops.use_pack_pool(self.pack_pool), _ops.use_grad_sinks():   # one batched re-pack of every conv weight, then lookups
+        if self.buffers.flat.is_cuda:
+            N.arena_reset(self.buffers.flat.device)          # scratch of the deferred split reductions: a step's worth
+        with _ops.use_pack_pool(self.pack_pool), _ops.use_grad_sinks(), _ops.deferred_reduce() as reductions:
+            # one batched re-pack of every conv weight, then lookups; the weight-gradient launches leave their split
+            # partials behind and ONE launch sums them all once the backward has been queued
             x, target = self.preprocess(raw, wiener)
             self.buffers.zero_grad()
             if self._buckets is None:
@@ -299,6 +303,8 @@ class Trainer:
                     loss, recon_error, perplexity = self.forward_loss(x, target)
                 loss.backward()                              # decoder, quantiser -> early bucket + d(latent)
                 self._cut = tap[0] if tap else None
+            if reductions:
+                N.wgrad_reduce_batch(reductions)
         return loss.detach(), recon_error.detach(), perplexity.detach()
 
     def _body_late(self):
@@ -307,8 +313,10 @@ class Trainer:
             return
         z, leaf = self._cut
         self._cut = None
-        with _ops.use_pack_pool(self.pack_pool, refresh=False), _ops.use_grad_sinks():
+        with _ops.use_pack_pool(self.pack_pool, refresh=False), _ops.use_grad_sinks(), _ops.deferred_reduce() as reductions:
             z.backward(leaf.grad)
+            if reductions:
+                N.wgrad_reduce_batch(reductions)
 
     def _sync_early(self):
         return self.buffers.sync_span(*self._buckets[0], group=self.group, force=self.force_collective) if self._buckets else None

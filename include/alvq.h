@@ -268,6 +268,26 @@ int alvq_conv1d_wgrad_bf16_multi(const void* const* dy, const void* const* x, in
  * with_bias: the single-segment launch that also produces dbias.  -1 for unsupported arguments. */
 int alvq_conv1d_wgrad_bf16_splits(int B, int C, int M, int L, int KW, int nseg, int with_bias);
 
+/* Deferred, batched split reduction (bf16 / fp16 family).  With accumulate = ALVQ_WGRAD_DEFER the four weight-gradient
+ * entry points of the family launch the contraction only: dw / dbias are not touched (dw may be NULL), the
+ * alvq_conv1d_wgrad_bf16_splits(...) partials stay at the start of `workspace` ([split][KW][M][C] fp32) and, for the
+ * single-segment launch with dbias != NULL, the bias partials ([split][pad64(M)] fp32) at
+ * workspace + alvq_conv1d_wgrad_bf16_bias_offset(...).  The caller gives every deferred launch its OWN workspace and later
+ * sums all of them with ONE alvq_wgrad_reduce_batch launch: per descriptor  dst (+)= scale * sum_s partial[s]  in split
+ * order -- the same sums in the same order as the immediate reduction (bitwise identical), as one launch that fills the
+ * chip instead of one small bandwidth-bound launch per layer.  A bias reduction is the descriptor
+ * {KW = 1, M = 1, C = channels, w_layout = ALVQ_W_OIK, stride = pad64(channels)}.  descs: HOST array. */
+#define ALVQ_WGRAD_DEFER 2
+int64_t alvq_conv1d_wgrad_bf16_bias_offset(int B, int C, int M, int L, int KW);
+typedef struct alvq_reduce_desc {
+  const float* partial;   /* [splits][stride] */
+  float* dst;             /* weight gradient in its native layout (w_layout), or a bias gradient */
+  const float* scale;     /* device scalar multiplied into the sum (undoes a loss scale), or NULL */
+  int32_t splits, KW, M, C, w_layout, accumulate;
+  int64_t stride;         /* elements between consecutive partials: KW * M * C, or the padded length of bias partials */
+} alvq_reduce_desc;
+int alvq_wgrad_reduce_batch(const alvq_reduce_desc* descs, int n, void* stream);
+
 /* ================================================================================================
  * Split-bf16 ("bf16x3") path: fp32-grade results on the bf16 matrix cores (gfx950 has no TF32/xf32 and its
  * exact-fp32 MFMA runs at 1/16 of the bf16 rate).  Every value is two bf16 planes, hi = bf16(v) and

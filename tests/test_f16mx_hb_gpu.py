@@ -92,3 +92,29 @@ def test_trainer_steps_track_the_f16mx_mode():
         losses[mode] = [float(tr.step(r)[0]) for r in raws]
     assert np.isfinite(losses["f16mx_hb"]).all()
     np.testing.assert_allclose(losses["f16mx_hb"], losses["f16mx"], rtol=5e-3)
+
+
+@pytest.mark.parametrize("mode", ["f16mx_hb", "bf16"])
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+@pytest.mark.parametrize("buckets", [1, 2])
+def test_deferred_batched_split_reduction_is_bitwise_the_immediate_one(mode, graph, buckets, monkeypatch):
+    """Inside a Trainer step the weight-gradient launches of the bf16 / fp16 family leave their split partials in arena
+    scratch and ONE launch sums them all at the end of the backward (alvq_wgrad_reduce_batch).  Same sums, same order:
+    the parameters after three steps are bit-identical to the per-launch reductions (ALVQ_DEFER_REDUCE=0)."""
+    from acoustic_locating_vq_vae.train_step import Trainer
+    cfg = (40, 1024, 16, 3, 256, 0.25, 64)            # wide enough for several splits per weight, both reduce layouts
+    raws = [torch.randn(4, 40, 60, generator=torch.Generator().manual_seed(20 + i)).cuda() for i in range(3)]
+    flats = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("ALVQ_DEFER_REDUCE", defer)
+        _ops.set_compute_dtype(mode)
+        m = _model(cfg, 9)
+        tr = Trainer(m, "speech", grad_buckets=buckets)
+        np.random.seed(5)
+        if graph:
+            tr.capture(raws[0], warmup=1)
+        for r in raws:
+            tr.step(r)
+        torch.cuda.synchronize()
+        flats[defer] = tr.buffers.flat.detach().clone()
+    assert torch.isfinite(flats["1"]).all() and torch.equal(flats["1"], flats["0"])
