@@ -64,6 +64,7 @@ struct ConvBArgs {
   // pass of the f16mx_hb mode: gradients under a loss scale, the H planes of f16mx activations and packed weights)
   int elem;
   const float* out_scale;   // OUT == 1: device scalar multiplied into the fp32 output (undoes a loss scale), or null
+  int* range_flag;          // fp16 outputs: sticky device flag, |= 4 when a stored value reached fp16's limit (or is a NaN)
 };
 
 constexpr int WP_ROWS = 256;   // packed weights are padded to this many rows per tap (largest m-tile)
@@ -110,6 +111,20 @@ __device__ __forceinline__ f32x4 elem_mfma16(const bf16x8_t& a, const bf16x8_t& 
   if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+
+// Saturation watch of fp16 outputs: `run` keeps the packed maximum of |half| over the words a lane stores (two VALU
+// instructions per word); fp16_limit_reached() is true if some half is >= 0x7BFF, i.e. 65504 (the saturating conversion's
+// ceiling) or a NaN.  One atomic per wave that saw one, at the end of its epilogue.
+__device__ __forceinline__ void fp16_watch(unsigned& run, unsigned word) {
+  const unsigned a = word & 0x7fff7fffu;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(run) : "v"(run), "v"(a));
+}
+__device__ __forceinline__ bool fp16_limit_reached(unsigned run) { return (run & 0xffffu) >= 0x7bffu || (run >> 16) >= 0x7bffu; }
+__device__ __forceinline__ void fp16_report(unsigned run, int* flag) {
+  if (flag && __any(fp16_limit_reached(run)) && (threadIdx.x & 63) == 0) atomicOr(flag, 4);
+}
+// defined in conv1d_f16mx.hip: device address of the format's sticky range flag on the current device
+int* fx_range_flag_ptr();
 
 // defined in conv1d_bf16_v2.hip: the 256x256-tile kernel for wide layers
 int conv1d_bf16_v2_launch(const ConvBArgs& a, int KW, hipStream_t stream);

@@ -283,6 +283,7 @@ static int conv1d_16bit(int elem, const float* out_scale, const void* x, const v
   a.relu = relu ? 1 : 0;
   a.elem = elem;
   a.out_scale = out_scale;
+  a.range_flag = elem ? fx_range_flag_ptr() : nullptr;
   // Wide layers: 256 x 256 tiles whenever the 256-wide m-tile is (nearly) full -- the width-3 kernel with the shared
   // activation slab, or the generic one; narrow or ragged M (128, 192, 201, 64, 1) stays on 128 x 128 tiles, which
   // waste less there and give more workgroups.  ALVQ_CONV_V2=0 / ALVQ_CONV_K3=0 force the fallbacks (used by

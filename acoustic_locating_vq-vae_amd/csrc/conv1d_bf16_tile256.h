@@ -83,6 +83,7 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
                                                    int kq, int wm0, int wn0) {
   static_assert(NMI % 2 == 0, "fragments are swapped in pairs");
   elem_saturate<F16>();
+  unsigned watch = 0;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   const int mb0 = m0 + wm0 + (kq & 1) * 16 + (kq >> 1) * 8;      // this lane's 8 channels of fragment pair 0
 #pragma unroll
@@ -158,6 +159,10 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
         for (int e = 0; e < 4; ++e) out[e] = ok ? out[e] : 0u;
       }
       *(u32x4*)(a.y + o) = out;
+      if (F16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fp16_watch(watch, out[e]);
+      }
       if (a.y2) {
         const u16x8 ps = *(const u16x8*)(a.post + o);
         u32x4 out2;
@@ -181,6 +186,7 @@ __device__ __forceinline__ void wave_epilogue_bf16(const ConvBArgs& a, const f32
       }
     }
   }
+  if (F16) fp16_report(watch, a.range_flag);
 }
 
 }  // namespace alvq

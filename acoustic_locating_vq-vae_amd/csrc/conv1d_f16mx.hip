@@ -31,6 +31,7 @@ struct ConvFxArgs {
   long x_plane, wp_plane, y_plane;    // element (u16) offsets from an H plane to its Q plane
   int ea, eb;                         // E8M0 scale exponents: weights (A operand), activations / gradients (B operand and outputs)
   const float* out_scale;             // OUT == 1: device scalar multiplied into the fp32 output (undoes a loss scale), or null
+  int* range_flag;                    // sticky device flag, |= 4 when a stored H reached fp16's limit
   unsigned long long* stamps;         // DBG instantiations, ALVQ_FX_DBG & 256: per workgroup {start, staged, main loop done, end} (100 MHz)
   int dbg;                            // switches of the DBG instantiations (ALVQ_FX_DBG), timing experiments only: 1 no in-loop
                                       // DMA, 2 no in-loop fragment reads, 4 no wait + barrier, 8 no epilogue, 16 / 32 no fp16 /
@@ -99,6 +100,7 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
   // constants 32 mi channels = 64 mi bytes of H, one Q chunk (64 bytes) per tile, 4 mi bytes of sign bits.
   const long qo0 = fx_q_off(cb0);
   FxEpiLoads ld[NIN];
+  unsigned watch = 0;
   // per row block, once (the row -> (b, l) division is ~20 VALU instructions): is this lane's row a data row; does the
   // block hold any row that is not
   bool okr[NIN], gapsr[NIN];
@@ -191,6 +193,8 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
     unsigned hw[8];
     if (DBG && (ax.dbg & 512)) fx_store16<true>(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v, hw);
     else fx_store16(a.y + hoff, (unsigned char*)(a.y + ax.y_plane) + qoff, s_hi, s_lo, v, hw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fp16_watch(watch, hw[e]);
     if (a.bits_out) *(unsigned short*)(a.bits_out + (hoff >> 3)) = (unsigned short)fx_sign_bits_of_h(hw);
     if (a.y2) {
       fx_load_add16(a.post + hoff, (const unsigned char*)(a.post + ax.y_plane) + qoff, s_lo, v);
@@ -218,6 +222,7 @@ __device__ __forceinline__ void wave_epilogue_fx(const ConvFxArgs& ax, const f32
     tile(NIN - 1, 2);
     tile(NIN - 1, 3);
   }
+  fp16_report(watch, ax.range_flag);
 }
 
 // DBG: 1 run-time ablation switches, 2 also no fp16 MFMAs, 3 also no fp8 MFMAs (timing experiments, tools/ablate_f16mx.sh).
@@ -492,8 +497,21 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
 // ------------------------------------------------------------------------------------------------ boundary conversions
 // Sticky range flag of the format (one int per device, in the code object's own data segment -- not an allocation):
 // bit 0 = a value of magnitude >= 65504 (fp16's largest finite value; it was stored saturated), bit 1 = a NaN, seen by a
-// conversion INTO the format (model inputs, gradients entering a backward chain).  Read / cleared by alvq_f16mx_range_flag.
+// conversion INTO the format (model inputs, gradients entering a backward chain); bit 2 = a value PRODUCED inside a chain
+// (an activation, or a loss-scaled gradient that outgrew the 2^8 headroom) reached the limit or is a NaN -- watched by
+// the epilogues of the f16mx and fp16 convolutions.  Read / cleared by alvq_f16mx_range_flag.
 __device__ int g_fx_range_flag = 0;
+
+int* fx_range_flag_ptr() {
+  static int* cache[64] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+  if (!cache[d]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fx_range_flag)) == hipSuccess) cache[d] = (int*)p;
+  }
+  return cache[d];
+}
 
 __global__ void fx_range_flag_kernel(int* out, int reset) {
   *out = g_fx_range_flag;
@@ -727,7 +745,7 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
                 (int)(rows / FX_R), pad_to(M, FX_M) / FX_M,   /* rtiles: see below */
                 (const unsigned char*)mask_bits, (unsigned char*)relu_bits_out},
                nlc_plane_elems(B, L, C), (long)alvq_packed_weight_elems(M, C, KW), nlc_plane_elems(B, L, M),
-               FX_E_W, FX_E_ACT, out_scale, nullptr, 0};
+               FX_E_W, FX_E_ACT, out_scale, fx_range_flag_ptr(), nullptr, 0};
 #ifdef ALVQ_DEBUG_KERNELS   // the ablation / phase-stamp instantiations exist only in the debug library (build.py --debug-kernels)
   static const int dbg_env = getenv("ALVQ_FX_DBG") ? atoi(getenv("ALVQ_FX_DBG")) : 0;   // timing ablations (results are garbage)
 #else

@@ -715,10 +715,11 @@ def grad_scale(x):
 
 
 def f16mx_range_flag(reset=True, device="cuda"):
-    """Sticky range flag of the f16mx format on the current device (one host sync): bit 0 = a value >= 65504 in magnitude
-    entered the format (it was stored saturated), bit 1 = a NaN did.  f16mx carries fp16's range: the precondition is
-    |activations| < 65504 (standardised spectrograms and Kaiming-scale weights stay orders of magnitude below); gradients
-    are brought into range by the device-chosen loss scale."""
+    """Sticky range flag of the f16mx / fp16 formats on the current device (one host sync): bit 0 = a value >= 65504 in
+    magnitude entered the format (it was stored saturated), bit 1 = a NaN did, bit 2 = a convolution PRODUCED such a value
+    (an activation, or a scaled gradient that outgrew its headroom).  The formats carry fp16's range: standardised
+    spectrograms and Kaiming-scale weights stay orders of magnitude below; gradients are brought into range by the
+    device-chosen loss scale.  0 = nothing saturated since the last reset."""
     out = device_flag(torch.device(device))
     _check(lib().alvq_f16mx_range_flag(out.data_ptr(), int(bool(reset)), _stream()), "alvq_f16mx_range_flag")
     return int(out.item())

@@ -329,9 +329,11 @@ int alvq_conv1d_wgrad_bf16x3_splits(int B, int C, int M, int L, int KW, int nseg
  *   alvq_conv1d_wgrad_f16mx  dw / dbias multiplied by *inv_scale (NULL = 1)
  *   alvq_f16mx_range_flag  *out (device int) = the format's sticky range flag of the current device, optionally cleared:
  *                          bit 0 = a value of magnitude >= 65504 entered the format (stored saturated: fp16 has no
- *                          larger finite value), bit 1 = a NaN entered it.  Set by alvq_ncl_to_nlc_f16mx (model inputs
- *                          and gradients entering a backward chain, after the loss scale).  Values produced INSIDE a
- *                          chain saturate the same way but are not flagged (precondition: activations below 65504).
+ *                          larger finite value), bit 1 = a NaN entered it (set by alvq_ncl_to_nlc_f16mx: model inputs
+ *                          and gradients entering a backward chain, after the loss scale); bit 2 = a value PRODUCED
+ *                          inside a chain reached the limit or is a NaN (an activation above 65504, a loss-scaled gradient
+ *                          that outgrew its 2^8 headroom) -- watched by the epilogues of alvq_conv1d_f16mx and
+ *                          alvq_conv1d_f16.  A set flag means "this step's results are fp16-saturated somewhere".
  * ============================================================================================== */
 int alvq_grad_scale_f32(const float* x, int64_t n, float* state, void* stream);
 int alvq_f16mx_range_flag(int* out, int reset, void* stream);

@@ -221,6 +221,15 @@ def test_range_flag_reports_inputs_outside_fp16s_range():
     g = torch.randn(2, 40, 33).cuda() * 1e7
     fx(g, N.grad_scale(g))
     assert N.f16mx_range_flag() == 0
+    # values PRODUCED inside a chain: a convolution whose output leaves fp16's range raises bit 2 (f16mx and fp16 kernels)
+    x = torch.full((2, 64, 40), 200.0).cuda()
+    w = torch.full((256, 64, 3), 1.0).cuda()                      # sums of 192 x 200 = 38 400 ... 76 800 at the edges / interior
+    N.conv1d_bf16(fx(x * 0.1), N.pack_weight(w, N.W_OIK, 3))     # 3 840 .. 7 680: in range
+    assert N.f16mx_range_flag() == 0
+    y = N.conv1d_bf16(fx(x * 2), N.pack_weight(w, N.W_OIK, 3))    # 76 800 .. : saturates
+    assert N.f16mx_range_flag() == 4 and float(N.nlc_to_ncl(y).max()) < 65505.0
+    N.conv1d_bf16(N.ncl_to_nlc(x * 2, 1, "f16"), N.pack_weight(w, N.W_OIK, 3))
+    assert N.f16mx_range_flag() == 4
 
 
 def test_relu_mask_f16mx():
