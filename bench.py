@@ -240,6 +240,8 @@ def main():
             except Exception as exc:                           # fall back to eager launches, and say so
                 launch = "eager (capture failed: %s)" % (str(exc).splitlines()[0][:120],)
                 trainer._graph = None
+        if dtype.startswith("f16mx"):
+            N.f16mx_range_flag(reset=True)
         elapsed, loss, summ = measure(trainer, raw, wiener, steps, warmup, timer and trainer._graph is None)
         if summ is None and timer:
             g_saved, gl_saved = trainer._graph, getattr(trainer, "_graph_late", None)
@@ -254,6 +256,9 @@ def main():
                "dtype": dtype, "launch": launch, "model_tflops": value * gf / 1e3,
                "step_frac_of_peak": value * gf / 1e3 / world / PEAK[dtype], "final_loss": loss,
                "allreduce_calls_per_step": (0 if world == 1 else (2 if trainer._buckets else 1))}
+        if dtype.startswith("f16mx"):
+            # 0 = no value entering or produced inside the fp16-range formats saturated during the timed steps
+            res["fp16_range_flag"] = N.f16mx_range_flag(reset=True)
         if summ is not None:
             res["roofline"] = roofline(summ, dtype)
             res["kernel_families"] = families(summ, summ_steps)
@@ -298,7 +303,7 @@ def main():
             "final_loss": head["final_loss"], "launch": head["launch"],
             "allreduce_calls_per_step": head["allreduce_calls_per_step"],
         }
-        for k in ("roofline", "kernel_families", "other_kernels_ms_per_step", "other_kernels_share"):
+        for k in ("roofline", "kernel_families", "other_kernels_ms_per_step", "other_kernels_share", "fp16_range_flag"):
             if k in head:
                 line[k] = head[k]
 
