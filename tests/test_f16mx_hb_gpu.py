@@ -60,10 +60,20 @@ def test_forward_is_f16mx_bit_for_bit_and_gradients_are_fp16_grade(cfg, shape, k
     print("f16mx_hb gradient rel-L2 vs f32, worst tensor: %.2e" % worst)
 
 
+@pytest.fixture
+def wide_min_tiles(request):
+    from acoustic_locating_vq_vae import _native as N
+    prev = N.set_option("wide_min_tiles", request.param)
+    yield request.param
+    N.set_option("wide_min_tiles", prev)
+
+
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
-def test_default_configs_against_reference_golden(tag, golden_dir):
+@pytest.mark.parametrize("wide_min_tiles", [192, 1], ids=["default_dispatch", "wide_forced"], indirect=True)
+def test_default_configs_against_reference_golden(tag, wide_min_tiles, golden_dir):
     """The north star's forward bar exactly as for f16mx (tests/test_default_configs_modes_gpu.py): indices bit-exact,
-    outputs 1e-3 (measured 2e-5), losses 1e-5; gradients at the fp16 bar."""
+    outputs 1e-3 (measured 2e-5), losses 1e-5; gradients at the bars of the split modes -- under the dispatch a user gets
+    (at the goldens' B = 2 the fp16 backward then runs the 128 x 128 kernel) and under the forced 256 x 256 kernels."""
     _ops.set_compute_dtype("f16mx_hb")
     r = run(tag, golden_dir)
     print("g3-%s f16mx_hb: %s" % (tag, json.dumps(r)))
@@ -73,7 +83,7 @@ def test_default_configs_against_reference_golden(tag, golden_dir):
         assert r["vq_loss_rel"] < 1e-5 and r["perplexity_rel"] < 1e-5, r
     assert r["recon_error_rel"] < 1e-5, r
     assert r["recon_rel_max"] < 1e-3 and r["recon_sum_rel"] < 1e-5, r
-    assert r["grad_rel_max"] < 0.15 and r["grad_rel_l2_max"] < 3e-2 and r["grad_rel_l2_median"] < 1e-2, r
+    assert r["grad_rel_max"] < 0.1 and r["grad_rel_l2_max"] < 1.5e-2 and r["grad_rel_l2_median"] < 5e-3 and r["grad_sum_rel_max"] < 3e-3, r
 
 
 def test_trainer_steps_track_the_f16mx_mode():
