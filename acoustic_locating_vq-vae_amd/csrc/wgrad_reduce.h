@@ -14,6 +14,37 @@ static __device__ __forceinline__ void wgrad_reduce_body(const float* partial, f
                                                          int nblk) {
   const long total = (long)KW * M * C;
   const float sc = scale ? *scale : 1.f;
+  if (w_layout == ALVQ_W_OIK && KW == 3) {
+    // One (m, c) pair per thread, its three taps together: the partials [split][t][m][c] are read with lanes along c
+    // (whole 256-byte runs per wave and tap, splits x 3 independent loads in flight) and the three outputs of a pair are
+    // adjacent in dw[m][c][t].  Indexing the OUTPUT instead (below) made neighbouring lanes read three different tap
+    // planes with a stride of three lanes: the batched reduction of a step ran at 3.9 TB/s.  Same sums, same split order.
+    const long pairs = (long)M * C;
+    for (long q = bid * 256L + threadIdx.x; q < pairs; q += (long)nblk * 256) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      const float* p = partial + q;
+      int k = 0;
+      for (; k + 2 <= splits; k += 2) {
+        const float* pa = p + (long)k * stride;
+        const float* pb = pa + stride;
+        const float a0 = pa[0], a1 = pa[pairs], a2 = pa[2 * pairs], b0 = pb[0], b1 = pb[pairs], b2 = pb[2 * pairs];
+        s0 = (s0 + a0) + b0;
+        s1 = (s1 + a1) + b1;
+        s2 = (s2 + a2) + b2;
+      }
+      for (; k < splits; ++k) {
+        const float* pa = p + (long)k * stride;
+        s0 += pa[0];
+        s1 += pa[pairs];
+        s2 += pa[2 * pairs];
+      }
+      if (scale) { s0 *= sc; s1 *= sc; s2 *= sc; }
+      float* o = dw + 3 * q;
+      if (accumulate) { s0 += o[0]; s1 += o[1]; s2 += o[2]; }
+      o[0] = s0; o[1] = s1; o[2] = s2;
+    }
+    return;
+  }
   for (long e = bid * 256L + threadIdx.x; e < total; e += (long)nblk * 256) {
     // e indexes the OUTPUT (coalesced writes); decode to (m, c, t)
     int m, c, t;
