@@ -21,6 +21,35 @@ struct PackBatch {
   long plane[PB_MAX];   // PLANES >= 2: element offset of the second image (bf16x3: lo; f16mx: Q)
 };
 
+// Eight consecutive channels (c .. c+7 of one packed row; `row_off` = element offset of the row in an image, `plane` =
+// element offset of the second image) in the format PLANES selects: 1 bf16; 2 bf16 hi + lo; 3 f16mx H + Q.
+template <int PLANES>
+__device__ __forceinline__ void pack_store8(u16* wp, long plane, long row_off, int c, const float (&v)[8]) {
+  const long o = row_off + c;
+  if (PLANES == 3) {   // f16mx: H image (fp16) + Q image ([hi8 x 32 | lo8 x 32] per 32 channels), weight-class scale
+    unsigned h[4], qh[2], ql[2];
+    fx_split<8>(v, fx_pow2(FX_E_W), fx_pow2(FX_E_W - FX_LO_SHIFT), h, qh, ql);
+    *(u32x4*)(wp + o) = u32x4{h[0], h[1], h[2], h[3]};
+    unsigned char* q = (unsigned char*)(wp + plane) + row_off * 2 + fx_q_off(c);
+    *(u32x2*)q = u32x2{qh[0], qh[1]};
+    *(u32x2*)(q + 32) = u32x2{ql[0], ql[1]};
+    return;
+  }
+  u32x4 hi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) hi[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
+  *(u32x4*)(wp + o) = hi;
+  if (PLANES == 2) {
+    u32x4 lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float h0 = __uint_as_float(hi[e] << 16), h1 = __uint_as_float(hi[e] & 0xffff0000u);
+      lo[e] = f2bf_pk(v[2 * e] - h0, v[2 * e + 1] - h1);
+    }
+    *(u32x4*)(wp + plane + o) = lo;
+  }
+}
+
 template <int PLANES>
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackBatch b) {
   __shared__ float tile[3][32][65];
@@ -52,32 +81,116 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackBatch b) {
   __syncthreads();
   const int mr = tid >> 3, cg = (tid & 7) * 8;
   for (int t = 0; t < KW; ++t) {
-    const long o = ((long)t * d.Mp + m0 + mr) * d.Cp + c0 + cg;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[t][mr][cg + e];
-    if (PLANES == 3) {   // f16mx: H image (fp16) + Q image ([hi8 x 32 | lo8 x 32] per 32 channels), weight-class scale
-      unsigned h[4], qh[2], ql[2];
-      fx_split<8>(v, fx_pow2(FX_E_W), fx_pow2(FX_E_W - FX_LO_SHIFT), h, qh, ql);
-      *(u32x4*)(d.wp + o) = u32x4{h[0], h[1], h[2], h[3]};
-      unsigned char* q = (unsigned char*)(d.wp + b.plane[di]) + ((long)t * d.Mp + m0 + mr) * d.Cp * 2 + fx_q_off(c0 + cg);
-      *(u32x2*)q = u32x2{qh[0], qh[1]};
-      *(u32x2*)(q + 32) = u32x2{ql[0], ql[1]};
-      continue;
+    pack_store8<PLANES>(d.wp, b.plane[di], ((long)t * d.Mp + m0 + mr) * d.Cp, c0 + cg, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Adam + packing in one pass (round 3; round-2 verdict item 4): the optimiser has every new weight in registers, so it
+// emits the packed image(s) the next step's convolutions read instead of a second kernel re-reading what it just wrote.
+// A workgroup owns a 32 (dim0) x 64 (dim1) x KW tile of one conv weight in its NATIVE layout: it reads w, g, m, v (lanes
+// along the contiguous (dim1, tap) axis), applies torch.optim.Adam's arithmetic -- the expression of adam_dev_kernel,
+// bit for bit -- writes w, m, v back, keeps the new w tile in LDS and writes it out as the image read OIK
+// (M = dim0, C = dim1) and / or the image read IOK (C = dim0, M = dim1, taps flipped), 16-byte runs along c.  Image
+// padding outside the weight's 32 x 64-rounded extent is not touched (it holds the zeros of the image's first full pack).
+constexpr int AP_MAX = 24;
+struct AdamPackDesc {
+  float* w; const float* g; float* m; float* v;
+  u16* oik; u16* iok;               // packed images or null
+  int dim0, dim1, KW, blk0, tiles1;
+  int oik_Mp, oik_Cp, iok_Mp, iok_Cp;
+};
+struct AdamPackBatch {
+  AdamPackDesc d[AP_MAX];
+  int n;
+  const float* sc;                  // {lr / bias_correction1, sqrt(bias_correction2), grad_scale} (alvq_adam_advance_f32)
+  float beta1, beta2, eps;
+};
+
+template <int PLANES>
+__global__ __launch_bounds__(256) void adam_pack_batch_kernel(AdamPackBatch b) {
+  __shared__ float tile[3][32][65];
+  if (PLANES == 3) fx_saturating_conversions();
+  int di = 0;
+  for (int i = 1; i < b.n; ++i)
+    if ((int)blockIdx.x >= b.d[i].blk0) di = i;
+  const AdamPackDesc& d = b.d[di];
+  const int lb = blockIdx.x - d.blk0;
+  const int r0 = (lb / d.tiles1) * 32, q0 = (lb % d.tiles1) * 64;       // tile origin along dim0 / dim1
+  const int KW = d.KW, tid = threadIdx.x;
+  const float lr_bc1 = b.sc[0], bc2_sqrt = b.sc[1], gscale = b.sc[2];
+  const float beta1 = b.beta1, beta2 = b.beta2, eps = b.eps;
+  const int run = 64 * KW;
+#pragma unroll 2
+  for (int e = tid; e < 32 * run; e += 256) {
+    const int rr = e / run, j = e - rr * run, qq = j / KW, t = j - qq * KW;
+    float wn = 0.f;
+    if (r0 + rr < d.dim0 && q0 + qq < d.dim1) {
+      const long i = ((long)(r0 + rr) * d.dim1 + q0) * KW + j;
+      const float gr = d.g[i] * gscale;
+      const float m0 = d.m[i], v0 = d.v[i];
+      const float mm = m0 + (gr - m0) * (1.f - beta1);
+      const float vv = v0 * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vv) / bc2_sqrt + eps;
+      d.m[i] = mm;
+      d.v[i] = vv;
+      wn = d.w[i] - lr_bc1 * (mm / denom);
+      d.w[i] = wn;
     }
-    u32x4 hi;
+    tile[t][rr][qq] = wn;
+  }
+  __syncthreads();
+  if (d.oik) {                     // image[t][m = dim0][c = dim1]
+    const int mr = tid >> 3, cg = (tid & 7) * 8;
+    const long plane = (long)KW * d.oik_Mp * d.oik_Cp;
+    for (int t = 0; t < KW; ++t) {
+      float v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) hi[e] = f2bf_pk(v[2 * e], v[2 * e + 1]);
-    *(u32x4*)(d.wp + o) = hi;
-    if (PLANES == 2) {
-      u32x4 lo;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float h0 = __uint_as_float(hi[e] << 16), h1 = __uint_as_float(hi[e] & 0xffff0000u);
-        lo[e] = f2bf_pk(v[2 * e] - h0, v[2 * e + 1] - h1);
-      }
-      *(u32x4*)(d.wp + b.plane[di] + o) = lo;
+      for (int e = 0; e < 8; ++e) v[e] = tile[t][mr][cg + e];
+      pack_store8<PLANES>(d.oik, plane, ((long)t * d.oik_Mp + r0 + mr) * d.oik_Cp, q0 + cg, v);
     }
+  }
+  if (d.iok) {                     // image[KW-1-k][m = dim1][c = dim0]
+    const int mr = tid >> 2, cg = (tid & 3) * 8;
+    const long plane = (long)KW * d.iok_Mp * d.iok_Cp;
+    for (int t = 0; t < KW; ++t) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[KW - 1 - t][cg + e][mr];
+      pack_store8<PLANES>(d.iok, plane, ((long)t * d.iok_Mp + q0 + mr) * d.iok_Cp, r0 + cg, v);
+    }
+  }
+}
+
+// Adam over the segments [lo, hi) of a flat buffer (the parameters the fused kernel above does not own: biases, the
+// codebook): same arithmetic, one launch; a block owns 1024 consecutive elements of one segment.
+constexpr int AS_MAX = 48;
+struct AdamSegs {
+  long lo[AS_MAX], hi[AS_MAX];
+  int blk0[AS_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void adam_segments_kernel(float* p, const float* g, float* m, float* v, AdamSegs s, const float* sc,
+                                                            float beta1, float beta2, float eps) {
+  int si = 0;
+  for (int i = 1; i < s.n; ++i)
+    if ((int)blockIdx.x >= s.blk0[i]) si = i;
+  const float lr_bc1 = sc[0], bc2_sqrt = sc[1], gscale = sc[2];
+  const long base = s.lo[si] + (long)(blockIdx.x - s.blk0[si]) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long e = base + k * 256 + threadIdx.x;
+    if (e >= s.hi[si]) return;
+    const float gr = g[e] * gscale;
+    const float mm = m[e] + (gr - m[e]) * (1.f - beta1);
+    const float vv = v[e] * beta2 + (1.f - beta2) * gr * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    m[e] = mm;
+    v[e] = vv;
+    p[e] = p[e] - lr_bc1 * (mm / denom);
   }
 }
 
@@ -113,6 +226,62 @@ extern "C" int alvq_pack_weights_bf16_batch(const alvq_pack_desc* descs, int n, 
     else if (planes == 2) hipLaunchKernelGGL(pack_weights_batch_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     else hipLaunchKernelGGL(pack_weights_batch_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     int rc = check_launch("alvq_pack_weights_bf16_batch");
+    if (rc) return rc;
+  }
+  return ALVQ_OK;
+}
+
+extern "C" int alvq_adam_pack_batch(const alvq_adam_pack_desc* descs, int n, int planes, const float* scalars, float beta1,
+                                    float beta2, float eps, void* stream) {
+  ALVQ_REQUIRE(descs && n > 0 && scalars, ALVQ_EINVAL, "alvq_adam_pack_batch: no descriptors / scalars");
+  ALVQ_REQUIRE(planes >= 1 && planes <= 3, ALVQ_EINVAL, "alvq_adam_pack_batch: planes=%d (1, 2 or 3)", planes);
+  for (int i = 0; i < n; ++i) {
+    const alvq_adam_pack_desc& s = descs[i];
+    ALVQ_REQUIRE(s.w && s.g && s.m && s.v, ALVQ_EINVAL, "alvq_adam_pack_batch: null pointer in descriptor %d", i);
+    ALVQ_REQUIRE(s.dim0 > 0 && s.dim1 > 0 && (s.KW == 1 || s.KW == 3), ALVQ_EINVAL, "alvq_adam_pack_batch: bad dims in descriptor %d", i);
+  }
+  for (int i0 = 0; i0 < n; i0 += AP_MAX) {
+    AdamPackBatch b{};
+    b.n = n - i0 < AP_MAX ? n - i0 : AP_MAX;
+    b.sc = scalars; b.beta1 = beta1; b.beta2 = beta2; b.eps = eps;
+    int blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const alvq_adam_pack_desc& s = descs[i0 + i];
+      AdamPackDesc& d = b.d[i];
+      d.w = s.w; d.g = s.g; d.m = s.m; d.v = s.v; d.oik = (u16*)s.wp_oik; d.iok = (u16*)s.wp_iok;
+      d.dim0 = s.dim0; d.dim1 = s.dim1; d.KW = s.KW;
+      d.oik_Mp = pad_to(s.dim0, WP_ROWS); d.oik_Cp = pad_to(s.dim1, TB_K);
+      d.iok_Mp = pad_to(s.dim1, WP_ROWS); d.iok_Cp = pad_to(s.dim0, TB_K);
+      d.blk0 = blocks; d.tiles1 = (s.dim1 + 63) / 64;
+      blocks += ((s.dim0 + 31) / 32) * d.tiles1;
+    }
+    if (planes == 1) hipLaunchKernelGGL(adam_pack_batch_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    else if (planes == 2) hipLaunchKernelGGL(adam_pack_batch_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL(adam_pack_batch_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    int rc = check_launch("alvq_adam_pack_batch");
+    if (rc) return rc;
+  }
+  return ALVQ_OK;
+}
+
+extern "C" int alvq_adam_segments_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* lo,
+                                      const int64_t* hi, int nseg, const float* scalars, float beta1, float beta2, float eps,
+                                      void* stream) {
+  ALVQ_REQUIRE(param && grad && exp_avg && exp_avg_sq && scalars && lo && hi, ALVQ_EINVAL, "alvq_adam_segments_f32: null pointer");
+  ALVQ_REQUIRE(nseg > 0, ALVQ_EINVAL, "alvq_adam_segments_f32: no segments");
+  for (int i0 = 0; i0 < nseg; i0 += AS_MAX) {
+    AdamSegs s{};
+    s.n = nseg - i0 < AS_MAX ? nseg - i0 : AS_MAX;
+    int blocks = 0;
+    for (int i = 0; i < s.n; ++i) {
+      ALVQ_REQUIRE(lo[i0 + i] >= 0 && hi[i0 + i] > lo[i0 + i], ALVQ_EINVAL, "alvq_adam_segments_f32: bad segment %d", i0 + i);
+      s.lo[i] = lo[i0 + i]; s.hi[i] = hi[i0 + i];
+      s.blk0[i] = blocks;
+      blocks += (int)((hi[i0 + i] - lo[i0 + i] + 1023) / 1024);
+    }
+    hipLaunchKernelGGL(adam_segments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, s, scalars,
+                       beta1, beta2, eps);
+    int rc = check_launch("alvq_adam_segments_f32");
     if (rc) return rc;
   }
   return ALVQ_OK;

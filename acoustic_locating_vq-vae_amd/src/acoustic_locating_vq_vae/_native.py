@@ -64,6 +64,8 @@ _SIGNATURES = {
     "alvq_packed_weight_elems": (_i64, [_i32, _i32, _i32]),
     "alvq_pack_weight_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_pack_weights_bf16_batch": (_i32, [_c_void_p, _i32, _i32, _c_void_p]),
+    "alvq_adam_pack_batch": (_i32, [_c_void_p, _i32, _i32, _c_void_p, _f32, _f32, _f32, _c_void_p]),
+    "alvq_adam_segments_f32": (_i32, [_c_void_p] * 4 + [_c_void_p, _c_void_p, _i32, _c_void_p, _f32, _f32, _f32, _c_void_p]),
     "alvq_ncl_to_nlc_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_nlc_to_ncl_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_relu_mask_bf16": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
@@ -817,6 +819,40 @@ def pack_weights_batch(entries, planes=1):
         d.w, d.wp, d.M, d.C, d.KW, d.w_layout = _ptr(w, name="w"), wp.data_ptr(), M, C, KW, w_layout
     _check(lib().alvq_pack_weights_bf16_batch(ctypes.addressof(arr), len(entries), planes, _stream()),
            "alvq_pack_weights_bf16_batch")
+
+
+class AdamPackDesc(ctypes.Structure):
+    """struct alvq_adam_pack_desc (include/alvq.h)"""
+    _fields_ = [("w", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("wp_oik", ctypes.c_void_p), ("wp_iok", ctypes.c_void_p), ("dim0", ctypes.c_int32), ("dim1", ctypes.c_int32),
+                ("KW", ctypes.c_int32)]
+
+
+def adam_pack_batch(entries, planes, scalars, beta1=0.9, beta2=0.999, eps=1e-8):
+    """entries: [(w, g, m, v fp32 views of one conv weight and its Adam state, packed OIK image or None, packed IOK image or
+    None)] -- Adam's update and the re-pack of every image in one launch."""
+    if not entries:
+        return
+    arr = (AdamPackDesc * len(entries))()
+    for d, (w, g, m, v, oik, iok) in zip(arr, entries):
+        d.w, d.g, d.m, d.v = _ptr(w, name="w"), _ptr(g, name="g"), _ptr(m, name="m"), _ptr(v, name="v")
+        d.wp_oik = oik.data_ptr() if oik is not None else None
+        d.wp_iok = iok.data_ptr() if iok is not None else None
+        d.dim0, d.dim1, d.KW = w.shape
+    _check(lib().alvq_adam_pack_batch(ctypes.addressof(arr), len(entries), planes, _ptr(scalars, name="scalars"), float(beta1),
+                                      float(beta2), float(eps), _stream()), "alvq_adam_pack_batch")
+
+
+def adam_segments(param, grad, exp_avg, exp_avg_sq, segments, scalars, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Adam over the element ranges [(lo, hi), ...] of the flat buffers, one launch."""
+    segments = [(int(a), int(b)) for a, b in segments if b > a]
+    if not segments:
+        return
+    lo = (ctypes.c_int64 * len(segments))(*[a for a, _ in segments])
+    hi = (ctypes.c_int64 * len(segments))(*[b for _, b in segments])
+    _check(lib().alvq_adam_segments_f32(_ptr(param, name="param"), _ptr(grad, name="grad"), _ptr(exp_avg, name="exp_avg"),
+                                        _ptr(exp_avg_sq, name="exp_avg_sq"), lo, hi, len(segments), _ptr(scalars, name="scalars"),
+                                        float(beta1), float(beta2), float(eps), _stream()), "alvq_adam_segments_f32")
 
 
 def relu_mask_bf16(dy, t):

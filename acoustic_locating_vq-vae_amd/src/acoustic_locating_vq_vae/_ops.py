@@ -137,6 +137,7 @@ class PackPool:
         self._dynamic = None if dynamic is None else {p.data_ptr() for p in dynamic}
         self._entries = {}          # (data_ptr, layout, planes) -> (packed image, tag)
         self._static_version = {}   # key -> parameter version the static image was packed at
+        self._adam_version = {}     # key -> parameter version at which the fused Adam + pack launch wrote the image
 
     def _is_static(self, ptr):
         return self._dynamic is not None and ptr not in self._dynamic
@@ -166,8 +167,15 @@ class PackPool:
             N.pack_weights_batch(entries, planes)
 
     def refresh(self):
-        """The step's batched re-pack: every image of a parameter the optimiser just updated."""
-        self._refresh([k for k in self._entries if not self._is_static(k[0])])
+        """The step's batched re-pack: every image of a parameter the optimiser updates -- EXCEPT the images the fused
+        Adam + pack launch wrote at the end of the previous step (``adam_groups`` / ``mark_adam_packed``), which are
+        already current unless someone has modified the parameter since (its version counter says so)."""
+        keys = [k for k in self._entries if not self._is_static(k[0]) and
+                self._adam_version.get(k) != self._eligible[k[0]]._version]
+        if keys:
+            self._refresh(keys)
+            for k in keys:
+                self._adam_version.pop(k, None)
 
     def refresh_static(self):
         """Host-side check, outside graph capture: re-pack a static image whose parameter was modified since."""
@@ -176,6 +184,30 @@ class PackPool:
             self._refresh(stale)
             for k in stale:
                 self._static_version[k] = self._eligible[k[0]]._version
+
+    def stale_dynamic(self):
+        """Dynamic images that a captured graph (which holds no re-pack of them) would read stale: written by the fused
+        Adam, parameter modified behind it since (load_state_dict, a broadcast).  The trainer re-packs them eagerly."""
+        return [k for k, v in self._adam_version.items() if self._eligible[k[0]]._version != v]
+
+    def adam_groups(self):
+        """({data_ptr: {layout: image}}, planes) over the dynamic entries, or (None, None) when they do not share one
+        format (then the optimiser and the re-pack stay separate launches)."""
+        groups, planes = {}, None
+        for (ptr, layout, pl), (img, _) in self._entries.items():
+            if self._is_static(ptr):
+                continue
+            if planes is None:
+                planes = pl
+            elif pl != planes:
+                return None, None
+            groups.setdefault(ptr, {})[layout] = img
+        return (groups, planes) if groups else (None, None)
+
+    def mark_adam_packed(self, ptrs):
+        for key in self._entries:
+            if key[0] in ptrs:
+                self._adam_version[key] = self._eligible[key[0]]._version
 
 
 _ACTIVE_POOL = None

@@ -132,10 +132,37 @@ class FlatAdam:
         self.step_count += 1
         N.adam_advance(self.scalars, self.lr, self.betas[0], self.betas[1], grad_scale)
 
-    def apply(self, skip=()):
+    def apply(self, skip=(), pack_pool=None):
         """One Adam launch over the flat buffer; ``skip`` = [lo, hi) element ranges that received no gradient this
         step (torch.optim.Adam leaves a parameter whose ``.grad`` is None untouched, moments included -- e.g. the
-        codebook under ``set_train_vq(False)``): the launch is then split around them."""
+        codebook under ``set_train_vq(False)``): the launch is then split around them.
+
+        ``pack_pool`` (a Trainer's ``_ops.PackPool``): the conv weights that have packed images in the pool are updated by
+        ONE fused launch that also writes those images while the new weights are in registers (``alvq_adam_pack_batch``;
+        round 2 re-read every weight in a separate packing launch at the start of the next step), everything else --
+        biases, the codebook -- by one segmented launch.  Same arithmetic, bit for bit."""
+        groups, planes = pack_pool.adam_groups() if (pack_pool is not None and os.environ.get("ALVQ_ADAM_PACK", "1") != "0") \
+            else (None, None)
+        if groups:
+            skipped = [(int(a), int(b)) for a, b in skip]
+            entries, segments, fused = [], [], set()
+            for p, off in zip(self.b.params, self.b.offsets):
+                n = p.numel()
+                if any(a <= off and off + n <= b for a, b in skipped):
+                    continue
+                imgs = groups.get(p.data_ptr()) if p.dim() == 3 else None
+                if imgs:
+                    entries.append((p.data, p.grad, self.exp_avg[off:off + n].view(p.shape), self.exp_avg_sq[off:off + n].view(p.shape),
+                                    imgs.get(N.W_OIK), imgs.get(N.W_IOK)))
+                    fused.add(p.data_ptr())
+                else:
+                    segments.append((off, off + n))
+            N.adam_pack_batch(entries, planes, self.scalars, self.betas[0], self.betas[1], self.eps)
+            N.adam_segments(self.b.flat, self.b.grad, self.exp_avg, self.exp_avg_sq, segments, self.scalars, self.betas[0],
+                            self.betas[1], self.eps)
+            pack_pool.mark_adam_packed(fused)
+            _ops.bump_weight_epoch()
+            return
         lo = 0
         for s_lo, s_hi in sorted(skip) + [(self.b.flat.numel(), self.b.flat.numel())]:
             if s_lo > lo:
@@ -329,7 +356,7 @@ class Trainer:
             for w in (early_work, late_work):
                 if w is not None:
                     w.wait()                                   # stream-level wait: the Adam launch queues behind both
-        self.opt.apply(self._adam_skip())                      # one Adam launch over the flat buffer
+        self.opt.apply(self._adam_skip(), self.pack_pool)      # Adam (+ the re-pack of the conv weights' images) over the flat buffer
 
     # ------------------------------------------------------------------------------------------- checkpoint / resume
     def state_dict(self):
@@ -361,6 +388,9 @@ class Trainer:
         self._check_frozen()
         if self.pack_pool is not None:
             self.pack_pool.refresh_static()        # frozen weights (echoed encoders): re-packed only if someone changed them
+            if self._graph is not None and self.pack_pool.stale_dynamic():
+                self.pack_pool.refresh()           # a parameter was modified behind the fused Adam's images (load_state_dict):
+                #                                    the replayed graph holds no re-pack of them
         if self._graph is None:
             self.opt.prepare(self.grad_scale)
             out = self._body(raw, wiener)

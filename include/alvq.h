@@ -231,6 +231,25 @@ typedef struct alvq_pack_desc {
 } alvq_pack_desc;
 int alvq_pack_weights_bf16_batch(const alvq_pack_desc* descs, int n, int planes, void* stream);
 
+/* Adam + packing in one pass (scripts/train_speech.py:154 + the re-pack above): for each conv weight (fp32, native
+ * layout (dim0, dim1, KW), with its gradient and Adam moments) apply torch.optim.Adam's update -- the arithmetic of
+ * alvq_adam_dev_f32, bit for bit, scalars = {lr/bias_correction1, sqrt(bias_correction2), grad_scale} on the device -- and
+ * write the updated weight's packed image read as OIK (wp_oik: M = dim0, C = dim1) and / or as IOK (wp_iok: C = dim0,
+ * M = dim1, taps flipped) while the new values are in registers.  Images must have been packed in full once before
+ * (their padding is not rewritten).  planes as in alvq_pack_weights_bf16_batch.  descs: HOST array. */
+typedef struct alvq_adam_pack_desc {
+  float* w; const float* g; float* m; float* v;
+  void* wp_oik; void* wp_iok;      /* either may be NULL */
+  int32_t dim0, dim1, KW;
+} alvq_adam_pack_desc;
+int alvq_adam_pack_batch(const alvq_adam_pack_desc* descs, int n, int planes, const float* scalars,
+                         float beta1, float beta2, float eps, void* stream);
+/* alvq_adam_dev_f32 over the nseg element ranges [lo[i], hi[i]) of flat buffers, one launch (lo / hi: HOST arrays): the
+ * parameters alvq_adam_pack_batch does not own (biases, the codebook). */
+int alvq_adam_segments_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                           const int64_t* lo, const int64_t* hi, int nseg, const float* scalars,
+                           float beta1, float beta2, float eps, void* stream);
+
 /* (B,C,L) fp32 -> NLC-padded bf16 (the boundary conversion for x, quantized and incoming gradients). */
 int alvq_ncl_to_nlc_bf16(const float* x, void* y, int B, int C, int L, void* stream);
 

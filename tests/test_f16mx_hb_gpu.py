@@ -128,3 +128,34 @@ def test_deferred_batched_split_reduction_is_bitwise_the_immediate_one(mode, gra
         torch.cuda.synchronize()
         flats[defer] = tr.buffers.flat.detach().clone()
     assert torch.isfinite(flats["1"]).all() and torch.equal(flats["1"], flats["0"])
+
+
+@pytest.mark.parametrize("mode", ["f16mx_hb", "bf16", "bf16x3", "f16mx"])
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+def test_fused_adam_pack_is_bitwise_adam_then_pack(mode, graph, monkeypatch):
+    """The optimiser launch that also emits the packed images of the conv weights (alvq_adam_pack_batch + one segmented
+    launch for biases / codebook) against the separate Adam and re-pack launches (ALVQ_ADAM_PACK=0): the same parameters,
+    bit for bit, after three steps -- and a load_state_dict between steps (parameters modified behind the fused images) is
+    picked up, in eager steps and under graph replay."""
+    from acoustic_locating_vq_vae.train_step import Trainer
+    cfg = (40, 200, 16, 2, 72, 0.25, 64)              # ragged channel counts: partially filled 32 x 64 tiles in both layouts
+    raws = [torch.randn(4, 40, 60, generator=torch.Generator().manual_seed(30 + i)).cuda() for i in range(4)]
+    flats, after_load = {}, {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ALVQ_ADAM_PACK", fused)
+        _ops.set_compute_dtype(mode)
+        m = _model(cfg, 13)
+        sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        tr = Trainer(m, "speech")
+        np.random.seed(5)
+        if graph:
+            tr.capture(raws[0], warmup=1)
+        for r in raws[:3]:
+            tr.step(r)
+        torch.cuda.synchronize()
+        flats[fused] = tr.buffers.flat.detach().clone()
+        m.load_state_dict(sd0)                        # back to the initial weights, behind the optimiser's back
+        loss = tr.step(raws[3])[0]
+        after_load[fused] = (float(loss), tr.buffers.flat.detach().clone())
+    assert torch.isfinite(flats["1"]).all() and torch.equal(flats["1"], flats["0"])
+    assert after_load["1"][0] == after_load["0"][0] and torch.equal(after_load["1"][1], after_load["0"][1])
