@@ -28,7 +28,6 @@ static const OptionSpec kSpecs[OPT_COUNT] = {
     {"conv_k3", "ALVQ_CONV_K3", 1},                   // bf16: the shared-slab width-3 kernel (0: the generic 256 x 256 one)
     {"wgrad_v3", "ALVQ_WGRAD_V3", 3},                 // bf16 weight gradient without bias: v3 kernels for width 1 (1) / width 3 (2)
     {"fx_k1_variant", "ALVQ_FX_K1", 1},               // f16mx width-1 conv: 0 round-2 kernel, 1 current
-    {"conv_alternate", "ALVQ_CONV_ALTERNATE", 0},     // convolution launches walk their row tiles alternately up / down
 };
 static std::atomic<long> g_opt[OPT_COUNT];
 static std::atomic<int> g_opt_ready{0};
@@ -43,11 +42,6 @@ static void options_init() {
 long option(int id) {
   options_init();
   return g_opt[id].load(std::memory_order_relaxed);
-}
-int conv_direction() {
-  static std::atomic<unsigned> n{0};
-  if (!option(OPT_CONV_ALTERNATE)) return 0;
-  return (int)(n.fetch_add(1, std::memory_order_relaxed) & 1u);
 }
 }  // namespace alvq
 

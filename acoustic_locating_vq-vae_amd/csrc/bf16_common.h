@@ -65,8 +65,6 @@ struct ConvBArgs {
   int elem;
   const float* out_scale;   // OUT == 1: device scalar multiplied into the fp32 output (undoes a loss scale), or null
   int* range_flag;          // fp16 outputs: sticky device flag, |= 4 when a stored value reached fp16's limit (or is a NaN)
-  int reverse;              // walk the row tiles from the last to the first (successive launches alternate: the rows a
-                            // launch wrote last are the ones most likely still in the Infinity Cache when the next reads them)
 };
 
 constexpr int WP_ROWS = 256;   // packed weights are padded to this many rows per tap (largest m-tile)

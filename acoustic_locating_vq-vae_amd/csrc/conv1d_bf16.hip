@@ -39,8 +39,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_bf16_kernel(ConvBArgs a) {
   const int li = lane & 15, kq = lane >> 4;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
 
-  const int tile0 = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int tile = a.reverse ? a.mtiles * a.rtiles - 1 - tile0 : tile0;
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
   const int m0 = (tile % a.mtiles) * TB_M;
   const int r0 = (tile / a.mtiles) * TB_R;
   const int Cp = a.Cp;
@@ -285,7 +284,6 @@ static int conv1d_16bit(int elem, const float* out_scale, const void* x, const v
   a.elem = elem;
   a.out_scale = out_scale;
   a.range_flag = elem ? fx_range_flag_ptr() : nullptr;
-  a.reverse = conv_direction();
   // Wide layers: 256 x 256 tiles whenever the 256-wide m-tile is (nearly) full -- the width-3 kernel with the shared
   // activation slab, or the generic one; narrow or ragged M (128, 192, 201, 64, 1) stays on 128 x 128 tiles, which
   // waste less there and give more workgroups.  ALVQ_CONV_V2=0 / ALVQ_CONV_K3=0 force the fallbacks (used by

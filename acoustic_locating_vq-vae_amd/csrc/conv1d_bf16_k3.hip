@@ -36,8 +36,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_k3_kernel(ConvBArgs a) {
   const int li = lane & 15, kq = lane >> 4;
   const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
 
-  const int tile0 = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int tile = a.reverse ? a.mtiles * a.rtiles - 1 - tile0 : tile0;
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);      // same tile order as the v2 kernel
   const int m0 = (tile % a.mtiles) * V2_M;
   const int r0 = (tile / a.mtiles) * V2_R;
   const int Cp = a.Cp;

@@ -40,8 +40,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16_v2_kernel(ConvBArgs a, int
   // tile order: all m-tiles of a row tile are neighbours, and each XCD owns a contiguous run of tiles, so the
   // workgroups resident on an XCD at one time share both operands through its L2 (W: one miss per m-tile per
   // wave of workgroups; activation rows: one miss per row tile instead of one per m-tile)
-  const int tile0 = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int tile = a.reverse ? a.mtiles * a.rtiles - 1 - tile0 : tile0;
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
   const int m0 = (tile % a.mtiles) * V2_M;
   const int r0 = (tile / a.mtiles) * V2_R;
   const int Cp = a.Cp;

@@ -243,8 +243,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 2) * 32 * MIN, wn0 = (wave & 3) * 32 * NIN;
 
-  const int tile0 = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int tile = a.reverse ? a.mtiles * a.rtiles - 1 - tile0 : tile0;
+  const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
   const int m0 = (tile % a.mtiles) * MT;
   const int r0 = (tile / a.mtiles) * RT;
   const int Cp = a.Cp;
@@ -753,7 +752,6 @@ extern "C" int alvq_conv1d_f16mx(const void* x, const void* wp, const float* bia
   constexpr int dbg_env = 0;
 #endif
   a.dbg = dbg_env;
-  a.b.reverse = conv_direction();
   hipStream_t s = (hipStream_t)stream;
   static DeviceOnce attr;
   if (attr.need()) {
