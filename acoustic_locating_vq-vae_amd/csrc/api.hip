@@ -27,7 +27,6 @@ static const OptionSpec kSpecs[OPT_COUNT] = {
     {"conv_v2", "ALVQ_CONV_V2", 1},                   // bf16: the 256 x 256-tile kernels at all
     {"conv_k3", "ALVQ_CONV_K3", 1},                   // bf16: the shared-slab width-3 kernel (0: the generic 256 x 256 one)
     {"wgrad_v3", "ALVQ_WGRAD_V3", 3},                 // bf16 weight gradient without bias: v3 kernels for width 1 (1) / width 3 (2)
-    {"fx_k1_variant", "ALVQ_FX_K1", 1},               // f16mx width-1 conv: 0 round-2 kernel, 1 current
 };
 static std::atomic<long> g_opt[OPT_COUNT];
 static std::atomic<int> g_opt_ready{0};

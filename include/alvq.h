@@ -51,7 +51,6 @@ const char* alvq_last_error(void);
  *   wgrad_v3 3           bf16 weight gradient without bias: v3 kernels for width 1 (bit 0) / width 3 (bit 1)
  *   fx_rows 0            f16mx conv row tile: 0 automatic, 128 or 256 forced
  *   fx_narrow 1          f16mx: 128-channel m-tile for fp32-NCL outputs of <= 128 channels
- *   fx_k1_variant 1      f16mx width-1 conv: 0 the round-2 kernel, 1 the current one
  * alvq_set_option returns ALVQ_EINVAL for an unknown name; alvq_get_option returns INT64_MIN. */
 int alvq_set_option(const char* name, int64_t value);
 int64_t alvq_get_option(const char* name);

@@ -114,6 +114,40 @@ def test_f16mx_conv_adjoint_wgrad_fullsize(C, M, KW):
     assert float((y - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("C,M,KW", SHAPES)
+def test_f16_backward_kernels_adjoint_wgrad_fullsize(C, M, KW):
+    """The fp16 kernels of the f16mx_hb backward at BASELINE's full sizes, fed exactly as the mode feeds them: a gradient as
+    one fp16 plane under its loss scale (magnitude 1e-6: far below fp16's range), the other operand the H plane of an f16mx
+    activation / packed weight.  Adjointness against the f16mx FORWARD launch (the pair the mode actually uses), the weight
+    gradient against the forward's derivative in W, and both against the exact-fp32 kernels at fp16-product precision."""
+    mag = 1e-6
+    x, dy = rnd(B, C, L, seed=41), rnd(B, M, L, seed=42, scale=mag)
+    W = rnd(M, C, KW, seed=43, scale=(C * KW) ** -0.5)
+    V = rnd(M, C, KW, seed=44, scale=(C * KW) ** -0.5)
+    gs = N.grad_scale(dy)
+    xn = N.ncl_to_nlc(x, 2, "f16mx")                        # saved forward activation
+    dyn = N.ncl_to_nlc(dy, 1, "f16", gs)                    # gradient entering the backward chain
+    y = N.conv1d_bf16(xn, N.pack_weight(W, N.W_OIK, 3), out_ncl=True)             # f16mx forward
+    dx = N.conv1d_bf16(dyn, N.pack_weight(W, N.W_IOK, 3), out_ncl=True)           # fp16 data gradient (H image of the weight)
+    assert tuple(dx.shape) == (B, C, L)
+
+    def close_scaled(lhs, rhs, a, b, tol):
+        """the inner product of independent random operands is ~sqrt(n) |a| |b| / n: judge the difference on that scale (a
+        relative bound on the inner product itself is at the mercy of how close to zero it happens to fall)"""
+        scale = float(a.double().norm() * b.double().norm()) / a.numel() ** 0.5
+        assert abs(lhs - rhs) <= tol * scale, (lhs, rhs, abs(lhs - rhs) / scale)
+
+    close_scaled(dot(y, dy), dot(x, dx), y, dy, 3e-3)       # fp16 products: 2^-12 rms per operand rounding
+    dW = N.conv1d_wgrad_bf16(dyn, xn, KW)                   # fp16 weight gradient (H plane of the activation)
+    yv = N.conv1d_bf16(xn, N.pack_weight(V, N.W_OIK, 3), out_ncl=True)
+    close_scaled(dot(dW, V), dot(yv, dy), yv, dy, 3e-3)
+    ref_dx = N.conv1d(dy, W, w_layout=N.W_IOK)
+    assert float((dx - ref_dx).abs().max()) <= 4e-3 * float(ref_dx.abs().max())
+    ref_dW = N.conv1d_wgrad(dy, x, KW)
+    assert float((dW - ref_dW).abs().max()) <= 4e-3 * float(ref_dW.abs().max())
+    assert N.f16mx_range_flag() == 0                        # nothing saturated on the way
+
+
 @pytest.mark.parametrize("KW", [1, 3])
 def test_f16mx_conv_sample_independence_and_gap_rows_fullsize(KW):
     C = M = 1024
@@ -226,7 +260,7 @@ def test_jitter_standardise_adam_fullsize():
 
 
 # ------------------------------------------------------------------------------------------------- the whole step
-@pytest.mark.parametrize("dtype", ["bf16", "bf16x3", "f16mx"])
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3", "f16mx", "f16mx_hb"])
 def test_train_step_invariants_fullsize(dtype):
     from acoustic_locating_vq_vae import _ops
     from acoustic_locating_vq_vae.train_step import Trainer
