@@ -227,11 +227,17 @@ class Trainer:
     kind="echoed":  x = standardise(echoed); x_rir = x^T; loss = mse(recon, x)                (train_echoed_speech.py)
     """
 
-    def __init__(self, model, kind="speech", lr=1e-3, group=None, grad_buckets=None, force_collective=None):
+    def __init__(self, model, kind="speech", lr=1e-3, group=None, grad_buckets=None, force_collective=None,
+                 range_check_every=None):
         """``force_collective`` (or ALVQ_FORCE_COLLECTIVE=1): issue the step's all-reduce even in a one-rank process
         group, where it is the identity -- so that the RCCL call between the backward and the Adam launch can be
         executed (and is tested, tests/test_rccl_gpu.py) on a single-GPU box."""
         self.model, self.kind, self.group = model, kind, group
+        # fp16-range formats (f16mx, f16mx_hb): every `range_check_every` steps (ALVQ_RANGE_CHECK_EVERY; default 200, 0 = never)
+        # the sticky range flag is read back -- ONE host sync -- and a set flag is reported: some value saturated at 65504
+        self.range_check_every = int(os.environ.get("ALVQ_RANGE_CHECK_EVERY", "200")) if range_check_every is None \
+            else int(range_check_every)
+        self._steps_since_check = 0
         self.force_collective = (os.environ.get("ALVQ_FORCE_COLLECTIVE", "0") != "0") if force_collective is None \
             else bool(force_collective)
         # echoed loop: the reference hands Adam every parameter (train_echoed_speech.py:48) but detaches both encoder
@@ -380,12 +386,32 @@ class Trainer:
             return []
         return [m for m in self.model.modules() if isinstance(m, Jitter)]
 
+    def check_range(self):
+        """Read (and clear) the fp16 range flag of the device: 0, or bits {1: an input reached 65504, 2: an input was NaN,
+        4: a convolution produced such a value}.  One host sync; ``step`` calls it every ``range_check_every`` steps in the
+        f16mx modes and warns."""
+        if not (self.buffers.flat.is_cuda and _ops.get_compute_dtype().startswith("f16mx")):
+            return 0
+        flag = N.f16mx_range_flag(reset=True, device=self.buffers.flat.device)
+        if flag:
+            import warnings
+            warnings.warn("acoustic_locating_vq_vae: fp16 range flag %d in mode %s -- a value entering or produced inside the "
+                          "fp16-range formats reached 65504 (or was NaN) since the last check; results of those steps are "
+                          "saturated.  ALVQ_DTYPE=bf16x3 or f32 have fp32 range." % (flag, _ops.get_compute_dtype()), RuntimeWarning)
+        return flag
+
     def step(self, raw, wiener=None):
-        """Returns (loss, recon_error, perplexity) as 0-dim device tensors -- no host sync in here.
+        """Returns (loss, recon_error, perplexity) as 0-dim device tensors -- no host sync in here (except the periodic
+        range check of the f16mx modes, every ``range_check_every`` steps).
 
         Order on the stream:  part 1 (fwd + decoder/quantiser backward)  ->  all-reduce(early bucket) starts  ->
         part 2 (encoder backward) runs while it is in flight  ->  all-reduce(late bucket)  ->  Adam."""
         self._check_frozen()
+        if self.range_check_every > 0:
+            self._steps_since_check += 1
+            if self._steps_since_check >= self.range_check_every:
+                self._steps_since_check = 0
+                self.check_range()
         if self.pack_pool is not None:
             self.pack_pool.refresh_static()        # frozen weights (echoed encoders): re-packed only if someone changed them
             if self._graph is not None and self.pack_pool.stale_dynamic():

@@ -159,3 +159,30 @@ def test_fused_adam_pack_is_bitwise_adam_then_pack(mode, graph, monkeypatch):
         after_load[fused] = (float(loss), tr.buffers.flat.detach().clone())
     assert torch.isfinite(flats["1"]).all() and torch.equal(flats["1"], flats["0"])
     assert after_load["1"][0] == after_load["0"][0] and torch.equal(after_load["1"][1], after_load["0"][1])
+
+
+def test_trainer_reports_fp16_saturation():
+    """Inputs far outside fp16's range: the Trainer's periodic range check (every step here) warns; sane inputs do not."""
+    import warnings
+    from acoustic_locating_vq_vae import _native as N
+    from acoustic_locating_vq_vae.train_step import Trainer
+    _ops.set_compute_dtype("f16mx_hb")
+    m = _model((20, 48, 8, 2, 24, 0.25, 64), 3, use_jitter=False)
+    with torch.no_grad():
+        m._encoder._conv_1.weight.mul_(3e4)          # activations of the first layer leave fp16's range
+    tr = Trainer(m, "speech", range_check_every=1)
+    N.f16mx_range_flag(reset=True)
+    raw = torch.randn(3, 20, 40, generator=torch.Generator().manual_seed(1)).cuda()
+    tr.step(raw)                                     # step 1 runs; the check at the START of step 2 sees its flag
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        tr.step(raw)
+    assert any("fp16 range flag" in str(x.message) for x in w), [str(x.message) for x in w]
+    m2 = _model((20, 48, 8, 2, 24, 0.25, 64), 3, use_jitter=False)
+    tr2 = Trainer(m2, "speech", range_check_every=1)
+    N.f16mx_range_flag(reset=True)
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        tr2.step(raw)
+        tr2.step(raw)
+    assert not any("fp16 range flag" in str(x.message) for x in w2)
