@@ -362,7 +362,10 @@ class Trainer:
             for w in (early_work, late_work):
                 if w is not None:
                     w.wait()                                   # stream-level wait: the Adam launch queues behind both
-        self.opt.apply(self._adam_skip(), self.pack_pool)      # Adam (+ the re-pack of the conv weights' images) over the flat buffer
+        if self.pack_pool is not None:                         # Adam + the re-pack of the conv weights' images in one launch
+            self.opt.apply(self._adam_skip(), pack_pool=self.pack_pool)
+        else:
+            self.opt.apply(self._adam_skip())                  # one Adam launch over the flat buffer
 
     # ------------------------------------------------------------------------------------------- checkpoint / resume
     def state_dict(self):
