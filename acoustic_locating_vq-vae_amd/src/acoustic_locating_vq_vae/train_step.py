@@ -464,13 +464,18 @@ class Trainer:
                 self._finish(early)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # capture_error_mode="thread_local": with a process group alive, ProcessGroupNCCL's watchdog THREAD polls the events
+        # of earlier collectives (hipEventQuery); under the default "global" mode such a call from another thread during
+        # the capture is an error that invalidates it (seen as an intermittent hipErrorStreamCaptureInvalidated in
+        # tests/test_rccl_gpu.py: about one capture in ten).  No collective is ever recorded into these graphs.
+        mode = os.environ.get("ALVQ_CAPTURE_MODE", "thread_local")
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             self._static_out = self._body(self._static_raw, self._static_wiener)
         graph_late = None
         if self._cut is not None:
             graph_late = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_late, pool=graph.pool()):
+            with torch.cuda.graph(graph_late, pool=graph.pool(), capture_error_mode=mode):
                 self._body_late()
         self._graph, self._graph_late = graph, graph_late
         return self
