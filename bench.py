@@ -145,8 +145,13 @@ def main():
     if backend != "nccl":
         local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    # ALVQ_FORCE_COLLECTIVE=1 at world 1: open a ONE-rank process group as well and let the Trainer issue its all-reduce
+    # (the identity there) -- a rehearsal of the N > 1 flow (process group, broadcast, capture next to the watchdog thread,
+    # collectives between graph replays and Adam) on a single GPU; tests/test_rccl_gpu.py runs it
+    force_pg = os.environ.get("ALVQ_FORCE_COLLECTIVE", "0") != "0"
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -158,7 +163,7 @@ def main():
     from acoustic_locating_vq_vae.train_step import Trainer
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -190,7 +195,7 @@ def main():
         dt = time.perf_counter() - t0
         if timer is not None:
             timer.__exit__()
-        if world > 1:
+        if world > 1 or force_pg:
             t = torch.tensor([dt], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -255,7 +260,7 @@ def main():
         res = {"value": value, "unit": "spectrograms/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
                "dtype": dtype, "launch": launch, "model_tflops": value * gf / 1e3,
                "step_frac_of_peak": value * gf / 1e3 / world / PEAK[dtype], "final_loss": loss,
-               "allreduce_calls_per_step": (0 if world == 1 else (2 if trainer._buckets else 1))}
+               "allreduce_calls_per_step": (0 if (world == 1 and not force_pg) else (2 if trainer._buckets else 1))}
         if dtype.startswith("f16mx"):
             # 0 = no value entering or produced inside the fp16-range formats saturated during the timed steps
             res["fp16_range_flag"] = N.f16mx_range_flag(reset=True)
@@ -308,7 +313,7 @@ def main():
                 line[k] = head[k]
 
     secondary = not args.no_secondary
-    if world > 1 and secondary and kind != "echoed":
+    if (world > 1 or force_pg) and secondary and kind != "echoed":
         # gradient exchange, measured both ways on this node: the north star's single all-reduce (the default) and the
         # two-span variant whose first span overlaps the encoder's backward
         alt, _, _ = run_config(kind, args.dtype, B, max(3, min(10, args.steps)), 2, graph=not args.no_graph, timer=False,
@@ -443,7 +448,7 @@ def main():
             blk["targets"] = "north_star: >=100x CPU, >=40% of the relevant roofline, indices bit-exact, outputs within 1e-3"
             line["north_star"] = blk
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 

@@ -66,6 +66,27 @@ def test_graph_capture_survives_the_process_group_watchdog():
     assert p.returncode == 0 and "RCCL_CAPTURE_STRESS 24" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+def test_bench_multi_gpu_flow_rehearsed_over_rccl_at_world_1():
+    """bench.py's N > 1 code path end to end on one GPU: a one-rank RCCL process group, every mode's Trainer broadcasting its
+    parameters, capturing its graphs next to the watchdog thread, issuing the forced all-reduce between the graph replays and
+    the Adam launch, the max-over-ranks reduction of the timing, both gradient-exchange settings -- and the same final loss
+    as the run without a process group."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "8", "--no-cpu-baseline",
+            "--no-parity", "--no-kernel-timer"]
+    outs = {}
+    for force in ("1", "0"):
+        p = subprocess.run(base, env=_env(ALVQ_FORCE_COLLECTIVE=force, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True,
+                           timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        outs[force] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    f, b = outs["1"], outs["0"]
+    assert f["allreduce_calls_per_step"] == 1 and b["allreduce_calls_per_step"] == 0
+    assert f["grad_exchange"]["two_spans"]["allreduce_calls_per_step"] == 2 and "grad_exchange" not in b
+    assert f["launch"] == "hipGraph replay" and f["final_loss"] == b["final_loss"]
+    for key in ("f16mx_parity_mode", "bf16x3_parity_mode", "f32_parity_mode", "bf16_throughput_mode"):
+        assert f[key]["allreduce_calls_per_step"] == 1 and f[key]["final_loss"] == b[key]["final_loss"], key
+
+
 def test_two_ranks_on_one_card_gloo():
     finals = {}
     for buckets in ("1", "2"):
