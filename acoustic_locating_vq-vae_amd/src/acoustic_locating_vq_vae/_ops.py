@@ -27,6 +27,12 @@ Two precisions share these chains through a small "engine" object:
   4.3e-4) -- in both modes the gradient error is set by the ~1e-5 forward noise flipping ReLU gates, not by the backward
   products -- at 0.72x the f16mx step time.
 
+* ``f16mx_hd`` -- (opt-in) f16mx_hb with the DECODER's forward on fp16 operands too (one fp16 plane per activation, one fp16
+  MFMA per product; the H image of the same packed weights).  Encoder, pre-VQ convolution and quantiser are f16mx_hb's bit
+  for bit, so the codebook indices stay bit-exact; the reconstruction carries fp16's operand rounding through ~10 layers:
+  5e-4 ... 7e-4 of the fp32 result at the default configs, 1.3e-3 measured on a 48-channel model -- at the north star's 1e-3,
+  not safely inside it -- and the decoder-side gradients see ~30x the ReLU gate flips.  0.87x the f16mx_hb step time.
+
 Select with ``set_compute_dtype(...)`` or the environment variable ``ALVQ_DTYPE``.
 DEFAULT (round 3): ``f16mx_hb`` -- the fastest mode that holds the reference's forward results (codebook indices
 bit-exact, outputs within 2e-5 on the default-config goldens), so that ``scripts/train_speech.py`` unchanged runs at ~7x
@@ -47,8 +53,8 @@ OIK, IOK = N.W_OIK, N.W_IOK
 
 DEFAULT_DTYPE = "f16mx_hb"
 _DTYPE = os.environ.get("ALVQ_DTYPE", DEFAULT_DTYPE)
-if _DTYPE not in ("f32", "bf16", "bf16x3", "f16mx", "f16mx_hb"):
-    raise ValueError("ALVQ_DTYPE must be 'f32', 'bf16', 'bf16x3', 'f16mx' or 'f16mx_hb', got %r" % (_DTYPE,))
+if _DTYPE not in ("f32", "bf16", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd"):
+    raise ValueError("ALVQ_DTYPE must be 'f32', 'bf16', 'bf16x3', 'f16mx', 'f16mx_hb' or 'f16mx_hd', got %r" % (_DTYPE,))
 
 
 def set_compute_dtype(name):
@@ -454,12 +460,37 @@ class _F16MXHBEngine(_F16MXEngine):
         return N.ncl_to_nlc(x, 2, "f16mx", None)
 
 
-_ENGINES = {"f32": _F32Engine, "bf16": _BF16Engine, "bf16x3": _BF16x3Engine, "f16mx": _F16MXEngine, "f16mx_hb": _F16MXHBEngine}
+class _F16MXHDEngine(_F16MXHBEngine):
+    """f16mx_hb with the DECODER's forward in fp16 as well (opt-in; module docstring): encoder, pre-VQ convolution and
+    quantiser -- everything the codebook indices depend on -- stay f16mx bit for bit; the decoder's activations are ONE fp16
+    plane and its products one fp16 MFMA each (the H image of the same packed weights)."""
+    name = "f16mx_hd"
+
+
+class _F16DecoderEngine(_F16MXHBEngine):
+    """The decoder's engine in the f16mx_hd mode: fp16 activations, fp16 gradients."""
+    name = "f16dec"
+    planes = 1
+    fmt = "f16"
+
+    def enter(self, x, grad=False):
+        x = dense(x)
+        return N.ncl_to_nlc(x, 1, "f16", N.grad_scale(x) if grad else None)
+
+
+_ENGINES = {"f32": _F32Engine, "bf16": _BF16Engine, "bf16x3": _BF16x3Engine, "f16mx": _F16MXEngine, "f16mx_hb": _F16MXHBEngine,
+            "f16mx_hd": _F16MXHDEngine}
 MODES = tuple(_ENGINES)
+_ROLE_ENGINES = {("f16mx_hd", "decoder"): _F16DecoderEngine}
+_ENGINES_BY_NAME = dict(_ENGINES, f16dec=_F16DecoderEngine)
 
 
-def _engine(name=None):
-    return _ENGINES[name or _DTYPE]()
+def _engine(name=None, role=None):
+    """The engine of the current mode (or, in a backward, the one that ran the node's forward); ``role`` lets a mode give
+    one part of the model its own arithmetic."""
+    if name is not None:
+        return _ENGINES_BY_NAME[name]()
+    return _ROLE_ENGINES.get((_DTYPE, role), _ENGINES[_DTYPE])()
 
 
 _ACT_TAP = None     # analysis hook (tools/gate_flips.py): a list that receives (engine name, saved activations) per node
@@ -690,7 +721,7 @@ class DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, src, wd, bd, w1, w2, wt1, bt1, wt2, bt2, wt3, bt3, R):
-        eng = _engine()
+        eng = _engine(role="decoder")
         _check_layers(R)
         q = dense(q)
         qj = eng.enter(N.jitter_gather(q, src) if src is not None else q)

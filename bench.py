@@ -17,6 +17,8 @@ What the line holds (N=1):
                             eager pass); `step_frac_of_peak` is the whole step's model FLOPs against the same peak
   bf16_throughput_mode .... plain bf16 storage + MFMA (what configs[1] literally names): faster, but ~1 % of the codebook
                             indices differ from the reference -- reported with that measured agreement, never as `value`
+  f16mx_hd_mode ........... opt-in: f16mx_hb with the decoder's forward on fp16 operands too -- indices still bit-exact, reconstruction
+                            fp16-grade (AT the 1e-3 tolerance, not safely inside it), reported with its measured errors, never as `value`
   parity .................. per mode: codebook-index agreement and z / recon / loss errors MEASURED IN THIS RUN on the
                             default-config golden made by the real reference (tests/golden/g3_speech.npz)
   north_star .............. the mode that carries the parity claim (bit-exact indices, 1e-3 forward): its throughput,
@@ -49,23 +51,26 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (N
 # product -> 1 / ((1/3) / 1250 + (2/3) / 2500) = 1875 TFLOP/s for the WHOLE step; each kernel family is judged against the
 # peak of its own arithmetic (FAMILY_PEAK).
 PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0,
-        "f16mx": BF16_MFMA_PEAK_TFLOPS / 2.0, "f16mx_hb": 1875.0}
+        "f16mx": BF16_MFMA_PEAK_TFLOPS / 2.0, "f16mx_hb": 1875.0, "f16mx_hd": 2200.0}
 FAMILY_PEAK = {"conv1d_f32_kernel": ("f32", F32_MFMA_PEAK_TFLOPS), "conv1d_wgrad_f32_kernel": ("f32", F32_MFMA_PEAK_TFLOPS),
                "conv1d_bf16x3_kernel": ("bf16x3", BF16_MFMA_PEAK_TFLOPS / 3.0), "conv1d_wgrad_bf16x3_kernel": ("bf16x3", BF16_MFMA_PEAK_TFLOPS / 3.0),
                "conv1d_f16mx_kernel": ("f16mx", BF16_MFMA_PEAK_TFLOPS / 2.0), "conv1d_wgrad_f16mx_kernel": ("f16mx", BF16_MFMA_PEAK_TFLOPS / 2.0)}
 PEAK_NOTE = {"f32": "exact-fp32 MFMA peak 157.3 TFLOP/s", "bf16": "dense bf16 (= fp16) MFMA peak 2500 TFLOP/s",
              "bf16x3": "2500/3 = 833.3 TFLOP/s algorithmic: three bf16 MFMAs per product",
              "f16mx": "2500/2 = 1250 TFLOP/s algorithmic: one fp16 MFMA + one block-scaled fp8 MFMA of equal duration per product",
-             "f16mx_hb": "whole step 1875 TFLOP/s = 1 / ((1/3)/1250 + (2/3)/2500): f16mx forward, one fp16 MFMA per backward product"}
+             "f16mx_hb": "whole step 1875 TFLOP/s = 1 / ((1/3)/1250 + (2/3)/2500): f16mx forward, one fp16 MFMA per backward product",
+             "f16mx_hd": "whole step 2200 TFLOP/s = 1 / (0.136/1250 + 0.864/2500): only the encoder's forward (13.6 of 99.95 GFLOP) at two units"}
 CONV_FAMILIES = {"f32": ("conv1d_f32_kernel", "conv1d_wgrad_f32_kernel"),
                  "bf16": ("conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel", "conv1d_wgrad_bf16_v2_kernel"),
                  "bf16x3": ("conv1d_bf16x3_kernel", "conv1d_wgrad_bf16x3_kernel"),
                  "f16mx": ("conv1d_f16mx_kernel", "conv1d_wgrad_f16mx_kernel"),
-                 "f16mx_hb": ("conv1d_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel")}
+                 "f16mx_hb": ("conv1d_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel"),
+                 "f16mx_hd": ("conv1d_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel")}
 MODE_TEXT = {"bf16": "bf16 storage + bf16 MFMA, fp32 accumulate / VQ / losses / master weights",
              "bf16x3": "split-bf16 (hi+lo planes, 3 bf16 MFMAs per product, fp32 accumulate)",
              "f16mx": "fp16 plane + fp8 (hi,lo) plane: one fp16 MFMA + one block-scaled fp8 MFMA per product, fp32 accumulate",
              "f16mx_hb": "f16mx forward (fp32-grade outputs) + fp16 backward (one fp16 MFMA per product under a loss scale, fp32 accumulate)",
+             "f16mx_hd": "f16mx encoder + quantiser forward, fp16 decoder forward, fp16 backward (opt-in)",
              "f32": "fp32 storage + exact-fp32 MFMA"}
 PARITY_MODES = ("f16mx_hb", "f16mx", "bf16x3")  # modes whose parity is bit-exact indices / <=1e-3 forward; the fastest carries the claim
 SPEECH_CFG = (201, 1024, 128, 3, 1024, 0.25, 1024)          # scripts/train_speech.py:152-153
@@ -120,7 +125,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU")
     ap.add_argument("--config", default="speech", choices=["speech", "rir", "echoed"],
                     help="speech = BASELINE configs[1] (the headline); rir = configs[2]; echoed = configs[4]")
-    ap.add_argument("--dtype", default="f16mx_hb", choices=["bf16", "f32", "bf16x3", "f16mx", "f16mx_hb"],
+    ap.add_argument("--dtype", default="f16mx_hb", choices=["bf16", "f32", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd"],
                     help="f16mx_hb (default): the fastest mode that holds the north star's parity -- f16mx forward (fp16 + "
                          "block-scaled fp8 MFMA per product), fp16 backward; f16mx: the cross terms in the backward too; bf16x3: "
                          "split-bf16 parity mode (3 bf16 MFMAs per product); f32: exact-fp32 MFMA; bf16: throughput mode (bf16 "
@@ -327,7 +332,7 @@ def main():
 
     if kind == "speech" and secondary:
         modes = {}
-        for mode in ("f16mx_hb", "f16mx", "bf16x3", "f32", "bf16"):
+        for mode in ("f16mx_hb", "f16mx", "bf16x3", "f32", "bf16", "f16mx_hd"):
             if mode == args.dtype:
                 modes[mode] = head
                 continue
@@ -336,15 +341,22 @@ def main():
                                            timer=not args.no_kernel_timer)
         if rank == 0:
             for mode, key in (("f32", "f32_parity_mode"), ("bf16x3", "bf16x3_parity_mode"), ("f16mx", "f16mx_parity_mode"),
-                              ("f16mx_hb", "f16mx_hb_parity_mode"), ("bf16", "bf16_throughput_mode")):
+                              ("f16mx_hb", "f16mx_hb_parity_mode"), ("bf16", "bf16_throughput_mode"),
+                              ("f16mx_hd", "f16mx_hd_mode")):
                 if mode != args.dtype:
                     line[key] = {k: v for k, v in modes[mode].items() if k != "kernel_families"}
             ns_mode = max(PARITY_MODES, key=lambda m: modes[m]["value"])
             line["_ns_src"] = (ns_mode, modes[ns_mode])
 
     if rank == 0 and world == 1 and kind == "speech" and not args.no_parity:
-        line["parity"] = {m: parity(m) for m in (["f16mx_hb", "f16mx", "bf16x3", "f32", "bf16"] if secondary else [args.dtype])}
+        line["parity"] = {m: parity(m) for m in (["f16mx_hb", "f16mx", "bf16x3", "f32", "bf16", "f16mx_hd"] if secondary else [args.dtype])}
         _ops.set_compute_dtype(args.dtype)
+        if "f16mx_hd_mode" in line and "f16mx_hd" in line["parity"]:
+            h = line["parity"]["f16mx_hd"]
+            line["f16mx_hd_mode"]["parity_note"] = (
+                "opt-in, not counted among the parity-holding modes: %d of %d codebook indices differ (the encoder side is "
+                "f16mx_hb's bit for bit), reconstruction rel-max %.2g -- fp16-grade, inside 1e-3 here but measured up to 1.3e-3 on "
+                "small models (tests/test_f16mx_hd_gpu.py)" % (h["idx_mismatches"], h["idx_total"], h["recon_rel_max"]))
         if "bf16_throughput_mode" in line and "bf16" in line["parity"]:
             b = line["parity"]["bf16"]
             line["bf16_throughput_mode"]["parity_note"] = (
