@@ -215,6 +215,25 @@ __global__ void adam_advance_kernel(float* sc, double lr, double beta1, double b
   sc[3] = (float)t;
 }
 
+
+// y[r] = mean_l x[r][l] (one wave per row; fixed-order sum: lane partials over l = lane, lane + 64, ... then the butterfly)
+__global__ __launch_bounds__(256) void row_mean_kernel(const float* x, float* y, long rows, int L) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* p = x + r * L;
+  float s = 0.f;
+  for (int l = lane; l < L; l += 64) s += p[l];
+  s = wave_sum(s);
+  if (lane == 0) y[r] = s / (float)L;
+}
+
+// dx[r][l] = dy[r] / L
+__global__ __launch_bounds__(256) void row_mean_backward_kernel(const float* dy, float* dx, long n, int L) {
+  const float inv = 1.f / (float)L;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dx[i] = dy[i / L] * inv;
+}
+
 }  // namespace alvq
 
 using namespace alvq;
@@ -285,6 +304,21 @@ extern "C" int alvq_relu_mask_f32(const float* dy, const float* t, float* out, i
   ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_relu_mask_f32: n <= 0");
   hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, t, out, (long)n);
   return check_launch("alvq_relu_mask_f32");
+}
+
+extern "C" int alvq_row_mean_f32(const float* x, float* y, int64_t rows, int L, void* stream) {
+  ALVQ_REQUIRE(x && y, ALVQ_EINVAL, "alvq_row_mean_f32: null pointer");
+  ALVQ_REQUIRE(rows > 0 && L > 0, ALVQ_EINVAL, "alvq_row_mean_f32: bad dims");
+  ALVQ_REQUIRE((rows + 3) / 4 < (1L << 31), ALVQ_EUNSUPPORTED, "alvq_row_mean_f32: too many rows");
+  hipLaunchKernelGGL(row_mean_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, L);
+  return check_launch("alvq_row_mean_f32");
+}
+
+extern "C" int alvq_row_mean_backward_f32(const float* dy, float* dx, int64_t rows, int L, void* stream) {
+  ALVQ_REQUIRE(dy && dx, ALVQ_EINVAL, "alvq_row_mean_backward_f32: null pointer");
+  ALVQ_REQUIRE(rows > 0 && L > 0, ALVQ_EINVAL, "alvq_row_mean_backward_f32: bad dims");
+  hipLaunchKernelGGL(row_mean_backward_kernel, dim3(ew_grid(rows * L)), dim3(256), 0, (hipStream_t)stream, dy, dx, (long)rows * L, L);
+  return check_launch("alvq_row_mean_backward_f32");
 }
 
 extern "C" int alvq_transpose_f32(const float* x, float* y, int B, int R, int C, void* stream) {

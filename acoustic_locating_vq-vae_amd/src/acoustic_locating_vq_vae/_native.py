@@ -48,6 +48,8 @@ _SIGNATURES = {
     "alvq_fill_f32": (_i32, [_c_void_p, _f32, _i64, _c_void_p]),
     "alvq_add_f32": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
     "alvq_relu_mask_f32": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
+    "alvq_row_mean_f32": (_i32, [_c_void_p] * 2 + [_i64, _i32, _c_void_p]),
+    "alvq_row_mean_backward_f32": (_i32, [_c_void_p] * 2 + [_i64, _i32, _c_void_p]),
     "alvq_transpose_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_adam_f32": (_i32, [_c_void_p] * 4 + [_i64, _i32, _f32, _f32, _f32, _f32, _f32, _c_void_p]),
     "alvq_adam_dev_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p, _f32, _f32, _f32, _c_void_p]),
@@ -544,6 +546,19 @@ def relu_mask(dy, t):
     out = torch.empty_like(dy)
     _check(lib().alvq_relu_mask_f32(_ptr(dy, name="dy"), _ptr(t, name="t"), _ptr(out), dy.numel(), _stream()), "alvq_relu_mask_f32")
     return out
+
+
+def row_mean(x, backward_of=None):
+    """mean over the last dimension, keepdim: (B, D, L) -> (B, D, 1).  ``backward_of`` = L: the adjoint, (B, D, 1) -> (B, D, L)."""
+    if backward_of is None:
+        B, D, L = x.shape
+        y = torch.empty((B, D, 1), device=x.device, dtype=torch.float32)
+        _check(lib().alvq_row_mean_f32(_ptr(x, name="x"), _ptr(y), B * D, L, _stream()), "alvq_row_mean_f32")
+        return y
+    B, D, _ = x.shape
+    dx = torch.empty((B, D, backward_of), device=x.device, dtype=torch.float32)
+    _check(lib().alvq_row_mean_backward_f32(_ptr(x, name="dy"), _ptr(dx), B * D, backward_of, _stream()), "alvq_row_mean_backward_f32")
+    return dx
 
 
 def transpose12(x):

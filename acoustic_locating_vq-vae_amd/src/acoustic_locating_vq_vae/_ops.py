@@ -788,6 +788,20 @@ class VQFn(torch.autograd.Function):
         return dx, (None if sink is not None else dE), None, None
 
 
+class MeanPoolFn(torch.autograd.Function):
+    """torch.mean(z, dim=2, keepdim=True): the optional pooling of the latent (convolutional_vq_vae.py:96-97)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = dense(z)
+        ctx.L = z.shape[2]
+        return N.row_mean(z)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return N.row_mean(dy.contiguous(), backward_of=ctx.L)
+
+
 class MSEFn(torch.autograd.Function):
     """F.mse_loss(a, b) (train_speech.py:74); b is a constant target."""
 

@@ -52,7 +52,7 @@ class ConvolutionalVQVAE(nn.Module):
             # first gradient bucket's all-reduce overlaps the second part: cut the autograd graph here.
             z = _ops.tap_latent(z)
         if self.encoder_average_pooling:
-            z = torch.mean(z, dim=2, keepdim=True)
+            z = _ops.MeanPoolFn.apply(z)
         loss, quantized, perplexity, _ = self._vq.quantize(z)
         x_recon = self._decoder(quantized)
         return loss, x_recon, perplexity

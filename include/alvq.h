@@ -150,6 +150,11 @@ int alvq_fill_f32(float* out, float value, int64_t n, void* stream);
 /* out = a + b (elementwise), used where a gradient has two consumers. */
 int alvq_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* y[r] = mean over L of x[r][0..L) and its backward dx[r][l] = dy[r] / L: the optional average pooling of the latent,
+ * torch.mean(z, dim=2, keepdim=True) (convolutional_vq_vae.py:96-97), with rows = B * D. */
+int alvq_row_mean_f32(const float* x, float* y, int64_t rows, int L, void* stream);
+int alvq_row_mean_backward_f32(const float* dy, float* dx, int64_t rows, int L, void* stream);
+
 /* out = t > 0 ? dy : 0: ReLU backward from the saved post-ReLU activation (F.relu, residual_stack.py:46). */
 int alvq_relu_mask_f32(const float* dy, const float* t, float* out, int64_t n, void* stream);
 

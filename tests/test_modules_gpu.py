@@ -138,12 +138,27 @@ def test_eval_mode_has_no_jitter_and_is_deterministic():
     assert rel(a, out["recon"]) < 1e-4
 
 
-def test_average_pooling_path_shapes():
-    m = build((7, 16, 4, 2, 8, 0.25, 16), encoder_average_pooling=True, out_channels=3).eval()
-    loss, recon, perp = m(torch.randn(5, 7, 13).cuda())
-    assert recon.shape == (5, 3, 1)
-    out = O.vqvae_forward(torch.randn(5, 7, 13), oracle_params(m), 2, 0.25, None, average_pooling=True)
+def test_average_pooling_path_matches_oracle():
+    """encoder_average_pooling=True (convolutional_vq_vae.py:96-97; no script enables it): the latent is averaged over time
+    by alvq_row_mean_f32 and its adjoint -- values and every gradient against the oracle, use_jitter=False (with jitter the
+    one-column latent raises in the reference and here alike, _ops.jitter_source_index)."""
+    torch.manual_seed(4)
+    m = build((7, 16, 4, 2, 8, 0.25, 16), encoder_average_pooling=True, out_channels=3, use_jitter=False).train()
+    with torch.no_grad():
+        m._vq._embedding.weight.normal_(0, 0.7)
+    p = oracle_params(m)
+    x = torch.randn(5, 7, 13)
+    target = torch.randn(5, 3, 1)
+    out = O.vqvae_forward(x, p, 2, 0.25, None, average_pooling=True)
     assert out["recon"].shape == (5, 3, 1)
+    (F.mse_loss(out["recon"], target) + out["vq_loss"]).backward()
+    vq_loss, recon, perp = m(x.cuda())
+    assert recon.shape == (5, 3, 1)
+    (F.mse_loss(recon, target.cuda()) + vq_loss).backward()
+    assert rel(recon, out["recon"]) < 1e-4 and rel(vq_loss, out["vq_loss"]) < 1e-5 and rel(perp, out["perplexity"]) < 1e-5
+    named = dict(m.named_parameters())
+    for k, v in p.items():
+        assert rel(named[k].grad, v.grad) < 1e-4, k
 
 
 def test_submodules_standalone():
