@@ -1,6 +1,8 @@
 """Loss curves of the arithmetic modes over a few hundred train steps of the speech config (same initial weights,
 same synthetic batches, jitter off so that the modes see identical inputs): do the split modes track fp32 beyond the
-handful of steps the parity tests cover?   python tools/long_run_modes.py [steps] [batch]"""
+handful of steps the parity tests cover?  The yardstick is the CONTROL leg "f32+ulp": the f32 mode itself, with the
+initial weights nudged by one part in 2^23 (a different-but-equally-exact fp32 run, e.g. another summation order) -- what
+it loses against f32 is the trajectory's own sensitivity, not arithmetic.   python tools/long_run_modes.py [steps] [batch]"""
 import os
 import sys
 
@@ -21,11 +23,15 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     pool = [torch.randn(B, 201, 500, device="cuda", generator=g).abs() * (1 + i % 3) for i in range(8)]
     curves = {}
-    modes = ("f32", "f16mx", "f16mx_hb", "bf16x3", "bf16")
+    modes = ("f32", "f32+ulp", "f16mx", "f16mx_hb", "f16mx_hd", "bf16x3", "bf16")
     for mode in modes:
-        _ops.set_compute_dtype(mode)
+        _ops.set_compute_dtype(mode.split("+")[0])
         torch.manual_seed(3)
         m = ConvolutionalVQVAE(*cfg, use_jitter=False).cuda().train()
+        if mode.endswith("+ulp"):
+            with torch.no_grad():
+                for q in m.parameters():
+                    q.mul_(1.0 + 2.0 ** -23)
         tr = Trainer(m, "speech")
         out = []
         for s in range(steps):
