@@ -420,7 +420,11 @@ class Trainer:
             if self._graph is not None and self.pack_pool.stale_dynamic():
                 self.pack_pool.refresh()           # a parameter was modified behind the fused Adam's images (load_state_dict):
                 #                                    the replayed graph holds no re-pack of them
-        if self._graph is None:
+        # a batch of another shape than the captured one (the ragged last batch of an epoch) runs as eager launches: the
+        # graphs' static buffers have one shape, and copy_ would broadcast a one-sample batch into them without a word
+        replay = self._graph is not None and tuple(raw.shape) == tuple(self._static_raw.shape) and \
+            (wiener is None or tuple(wiener.shape) == tuple(self._static_wiener.shape))
+        if not replay:
             self.opt.prepare(self.grad_scale)
             out = self._body(raw, wiener)
             early = self._sync_early()

@@ -328,6 +328,39 @@ def test_graph_replay_equals_eager_steps():
     assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16mx_hb"])
+def test_ragged_batch_after_capture_runs_eagerly(mode):
+    """The last batch of an epoch is smaller than the captured one: it must run (as eager launches) with exactly the result
+    a Trainer without graphs gives, and the replays must carry on afterwards.  A one-sample batch is the nasty case: copy_
+    into the graph's static buffer would broadcast it over the whole batch without an error."""
+    from acoustic_locating_vq_vae import _ops
+    from acoustic_locating_vq_vae.train_step import Trainer
+    cfg = (20, 48, 8, 2, 24, 0.25, 64)
+    gen = lambda b, s: torch.randn(b, 20, 40, generator=torch.Generator().manual_seed(s)).cuda()
+    seq = [gen(4, 1), gen(3, 2), gen(4, 3), gen(1, 4), gen(4, 5)]
+    finals = []
+    _ops.set_compute_dtype(mode)
+    try:
+        for use_graph in (False, True):
+            torch.manual_seed(7)
+            m = build(cfg, use_jitter=False)
+            with torch.no_grad():
+                m._vq._embedding.weight.normal_(0, 0.7)
+            m.train()
+            tr = Trainer(m, "speech")
+            if use_graph:
+                tr.capture(gen(4, 0), warmup=2)
+            else:
+                for _ in range(2):
+                    tr.step(gen(4, 0))
+            losses = [float(tr.step(r)[0]) for r in seq]
+            finals.append((losses, tr.buffers.flat.clone()))
+    finally:
+        _ops.set_compute_dtype("f32")
+    assert np.allclose(finals[0][0], finals[1][0], rtol=1e-5), (finals[0][0], finals[1][0])
+    assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-5
+
+
 def test_graph_replay_survives_workspace_growth():
     """A captured graph records the raw pointer of the scratch its weight-gradient / quantiser launches used.  A later
     eager call that needs MORE scratch (a bigger batch, another model, another dtype -- bench.py does all three) must
