@@ -342,6 +342,11 @@ def _need_gpu(x, who):
     if not x.is_cuda:
         raise RuntimeError("%s: input is on %s -- this build runs the HIP path only (no CPU fallback); "
                            "move the model and data to the GPU" % (who, x.device))
+    # one process per GPU: the launches go to the CURRENT device's stream, so a tensor that lives on another card would
+    # be handed to a kernel running elsewhere -- refuse instead (torch's own ops switch devices under the hood; these do not)
+    if x.device.index is not None and x.device.index != torch.cuda.current_device():
+        raise RuntimeError("%s: input is on %s but the current device is cuda:%d -- call torch.cuda.set_device(%d) "
+                           "(one process per GPU)" % (who, x.device, torch.cuda.current_device(), x.device.index))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -99,6 +99,22 @@ def test_forward_on_cpu_fails_loudly():
         VectorQuantizer(16, 4, 0.25)(torch.randn(2, 4, 6))
 
 
+def test_tensor_on_another_card_is_refused(monkeypatch):
+    """One process per GPU: the kernels are launched on the current device's stream, so an input living on another card
+    must raise instead of being handed to a kernel that runs elsewhere (stand-in tensor: this test needs no GPU)."""
+    from acoustic_locating_vq_vae import _ops
+
+    class OnCard1:
+        is_cuda = True
+        device = torch.device("cuda", 1)
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    with pytest.raises(RuntimeError, match=r"set_device\(1\)"):
+        _ops._need_gpu(OnCard1(), "ConvolutionalVQVAE")
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    _ops._need_gpu(OnCard1(), "ConvolutionalVQVAE")
+
+
 def test_echoed_model_surface():
     from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
     rir = make((20, 16, 4, 2, 8, 0.25, 16), use_jitter=False, out_channels=1)
