@@ -173,6 +173,13 @@ def big(tag, cfg, shape, permuted, out_channels, use_jitter, cb_scale):
           "min rel gap", gap.min(), "n<1e-4", int((gap < 1e-4).sum()))
 
 
+def speech_b16():
+    """Round 3: the speech config at a training-like batch (8000 codebook rows).  At B = 2 a flipped ReLU gate is one of 1000
+    terms of a weight-gradient element; this golden shows the split modes' gradient agreement where the batch averages the
+    flips down (tools/gate_flips.py predicts ~1/sqrt(B)) -- and eight times as many indices that must all be bit-exact."""
+    big("speech_b16", (201, 1024, 128, 3, 1024, 0.25, 1024), (16, 201, 500), False, None, True, SPEECH_CB)
+
+
 def g3_echoed():
     from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
     from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
@@ -285,6 +292,7 @@ if __name__ == "__main__":
     g2_vq()
     big("speech", (201, 1024, 128, 3, 1024, 0.25, 1024), (2, 201, 500), False, None, True, SPEECH_CB)
     big("rir", (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False, RIR_CB)
+    speech_b16()
     g3_echoed()
     g5_jitter()
     g6_stft()

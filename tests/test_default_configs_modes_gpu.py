@@ -68,6 +68,35 @@ def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_
         assert r["encoders_grad_free"]
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd", "bf16"], indirect=True)
+def test_speech_config_at_a_training_batch_against_reference_golden(mode, golden_dir):
+    """G3-speech at B = 16 (round 3; made by the real reference): 8 000 codebook rows, 22 of them with a relative top-2
+    distance gap below 1e-4 and the smallest at 6.9e-6 -- every parity mode must still return ALL 8 000 indices of the
+    reference -- and gradients where a flipped ReLU gate is one of 8 000 terms instead of one of 1 000: the split modes'
+    max-norm error falls from 4e-2 (B = 2) to 1e-2, as tools/gate_flips.py's 1/sqrt(B) says.
+    Measured: f32 0 / 8000, z 1.6e-6, grads 9.8e-4; bf16x3 0, 7e-6, 2.7e-2 (rel-L2 median 1.4e-4); f16mx = f16mx_hb 0, 1.5e-5,
+    recon 2.3e-5, grads 1.0e-2 (median 1.6e-4 / 5.9e-4); f16mx_hd recon 6.7e-4; bf16 68 differ (99.15 %)."""
+    r = run("speech_b16", golden_dir)
+    print("g3-speech_b16 %s: %s" % (mode, json.dumps(r)))
+    assert r["idx_total"] == 8000 and r["slice_elems"] >= 4096
+    if mode == "bf16":
+        assert r["idx_agree"] >= 0.985 and r["mismatch_gap_max"] < 5e-3, r
+        assert r["z_rel_l2"] < 1.5e-2 and r["recon_error_rel"] < 1e-2 and r["grad_rel_l2_median"] < 0.3, r
+        return
+    assert r["idx_mismatches"] == 0, r
+    assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-5 and r["vq_loss_rel"] < 1e-5 and r["perplexity_rel"] < 1e-5, r
+    assert r["recon_error_rel"] < 1e-5, r
+    if mode == "f16mx_hd":
+        assert r["recon_rel_max"] < 1e-3 and r["grad_rel_max"] < 0.1 and r["grad_rel_l2_median"] < 1e-2, r
+        return
+    assert r["recon_rel_max"] < 1e-4 and r["recon_sum_rel"] < 1e-5, r
+    if mode == "f32":
+        assert r["grad_rel_max"] < 3e-3 and r["grad_rel_l2_max"] < 1e-3 and r["grad_sum_rel_max"] < 1e-4, r
+    else:
+        assert r["grad_rel_max"] < 5e-2 and r["grad_rel_l2_max"] < 3e-2 and r["grad_rel_l2_median"] < 2e-3, r
+        assert r["grad_sum_rel_max"] < 5e-4 and r["encoder_grad_rel_max"] < 2e-2, r
+
+
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
 @pytest.mark.parametrize("mode", ["f16mx_hd"], indirect=True)
 def test_half_decoder_mode_default_configs_against_reference_golden(mode, tag, golden_dir):

@@ -125,13 +125,13 @@ def test_g6_stft_unpinned(golden_dir):
     assert g["power_f32"].shape == (1, 201, 26)
 
 
-@pytest.mark.parametrize("tag", ["speech", "rir"])
+@pytest.mark.parametrize("tag", ["speech", "rir", "speech_b16"])
 def test_g3_default_configs(golden_dir, tag):
-    """Default speech / RIR configs at B=2 (about 10 s of CPU)."""
+    """Default speech / RIR configs at B=2 (about 10 s of CPU); the speech config at B=16 (8 000 codebook rows, ~25 s)."""
     g = load(golden_dir, "g3_%s.npz" % tag)
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
-    if tag == "speech":
-        cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (2, 201, 500), False, None, True
+    if tag.startswith("speech"):
+        cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (16 if tag.endswith("b16") else 2, 201, 500), False, None, True
     else:
         cfg, shape, permuted, oc, jit = (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False
     in_c, h, d, r, rh, beta, k = cfg
