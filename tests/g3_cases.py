@@ -90,12 +90,12 @@ def _grad_report(named_params, g, prefix=""):
 
 
 def run_vqvae(tag, golden_dir=GOLDEN):
-    """tag in {"speech", "speech_b16", "rir"}.  Returns the parity numbers of the current compute dtype against the golden."""
+    """tag in {"speech", "speech_b16", "speech_b64", "rir"}.  Returns the parity numbers of the current compute dtype against the golden."""
     g = np.load(os.path.join(golden_dir, "g3_%s.npz" % tag))
     if tag == "speech":
         cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (2, 201, 500), False, None, True
-    elif tag == "speech_b16":
-        cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (16, 201, 500), False, None, True
+    elif tag in ("speech_b16", "speech_b64"):
+        cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (int(tag[-2:]), 201, 500), False, None, True
     else:
         cfg, shape, permuted, oc, jit = (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False
     in_c, h, d, r, rh, beta, k = cfg

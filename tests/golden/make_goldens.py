@@ -180,6 +180,11 @@ def speech_b16():
     big("speech_b16", (201, 1024, 128, 3, 1024, 0.25, 1024), (16, 201, 500), False, None, True, SPEECH_CB)
 
 
+def speech_b64():
+    """Round 3: the bench workload itself -- BASELINE configs[1], B = 64, 32 000 codebook rows."""
+    big("speech_b64", (201, 1024, 128, 3, 1024, 0.25, 1024), (64, 201, 500), False, None, True, SPEECH_CB)
+
+
 def g3_echoed():
     from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
     from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
@@ -293,6 +298,7 @@ if __name__ == "__main__":
     big("speech", (201, 1024, 128, 3, 1024, 0.25, 1024), (2, 201, 500), False, None, True, SPEECH_CB)
     big("rir", (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False, RIR_CB)
     speech_b16()
+    speech_b64()
     g3_echoed()
     g5_jitter()
     g6_stft()

@@ -97,6 +97,35 @@ def test_speech_config_at_a_training_batch_against_reference_golden(mode, golden
         assert r["grad_sum_rel_max"] < 5e-4 and r["encoder_grad_rel_max"] < 2e-2, r
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd", "bf16"], indirect=True)
+def test_the_bench_workload_against_reference_golden(mode, golden_dir):
+    """G3-speech at B = 64: BASELINE configs[1] itself -- the batch bench.py times -- run by the real reference on the CPU
+    (tests/golden/g3_speech_b64.npz: 32 000 codebook rows, 92 of them with a relative top-2 gap below 1e-4, the smallest
+    4.2e-6).  Every parity mode must return ALL 32 000 reference indices, outputs at the north star's bar, and gradients at
+    the level a training batch gives (a flipped ReLU gate is one of 32 000 terms).
+    Measured: f32 0 / 32000, z 1.5e-6, grads max-norm 1.7e-3; bf16x3 0, 6.6e-6, 6.2e-3; f16mx = f16mx_hb 0, 1.8e-5, recon
+    1.9e-5, grads 5.0e-3 / 4.4e-3 (rel-L2 median 1.3e-4 / 3.6e-4); f16mx_hd recon 6.2e-4, grads 2.3e-2; bf16 264 differ."""
+    r = run("speech_b64", golden_dir)
+    print("g3-speech_b64 %s: %s" % (mode, json.dumps(r)))
+    assert r["idx_total"] == 32000 and r["slice_elems"] >= 4096
+    if mode == "bf16":
+        assert r["idx_agree"] >= 0.985 and r["mismatch_gap_max"] < 5e-3, r
+        assert r["z_rel_l2"] < 1.5e-2 and r["recon_error_rel"] < 1e-2 and r["grad_rel_l2_median"] < 0.2, r
+        return
+    assert r["idx_mismatches"] == 0, r
+    assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-5 and r["vq_loss_rel"] < 1e-5 and r["perplexity_rel"] < 1e-5, r
+    assert r["recon_error_rel"] < 1e-5, r
+    if mode == "f16mx_hd":
+        assert r["recon_rel_max"] < 1e-3 and r["grad_rel_max"] < 0.1 and r["grad_rel_l2_median"] < 1e-2, r
+        return
+    assert r["recon_rel_max"] < 1e-4 and r["recon_sum_rel"] < 1e-5, r
+    if mode == "f32":
+        assert r["grad_rel_max"] < 5e-3 and r["grad_rel_l2_max"] < 1e-3 and r["grad_sum_rel_max"] < 1e-4, r
+    else:
+        assert r["grad_rel_max"] < 2e-2 and r["grad_rel_l2_max"] < 1.5e-2 and r["grad_rel_l2_median"] < 1e-3, r
+        assert r["grad_sum_rel_max"] < 5e-4 and r["encoder_grad_rel_max"] < 1e-2, r
+
+
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
 @pytest.mark.parametrize("mode", ["f16mx_hd"], indirect=True)
 def test_half_decoder_mode_default_configs_against_reference_golden(mode, tag, golden_dir):

@@ -125,13 +125,14 @@ def test_g6_stft_unpinned(golden_dir):
     assert g["power_f32"].shape == (1, 201, 26)
 
 
-@pytest.mark.parametrize("tag", ["speech", "rir", "speech_b16"])
+@pytest.mark.parametrize("tag", ["speech", "rir", "speech_b16", "speech_b64"])
 def test_g3_default_configs(golden_dir, tag):
-    """Default speech / RIR configs at B=2 (about 10 s of CPU); the speech config at B=16 (8 000 codebook rows, ~25 s)."""
+    """Default speech / RIR configs at B=2 (about 10 s of CPU); the speech config at B=16 and at the
+    bench batch B=64 (8 000 / 32 000 codebook rows; a few seconds each on 8 cores)."""
     g = load(golden_dir, "g3_%s.npz" % tag)
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     if tag.startswith("speech"):
-        cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (16 if tag.endswith("b16") else 2, 201, 500), False, None, True
+        cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (int(tag[-2:]) if tag[-2:].isdigit() else 2, 201, 500), False, None, True
     else:
         cfg, shape, permuted, oc, jit = (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False
     in_c, h, d, r, rh, beta, k = cfg
