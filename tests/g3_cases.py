@@ -90,14 +90,14 @@ def _grad_report(named_params, g, prefix=""):
 
 
 def run_vqvae(tag, golden_dir=GOLDEN):
-    """tag in {"speech", "speech_b16", "speech_b64", "rir"}.  Returns the parity numbers of the current compute dtype against the golden."""
+    """tag in {"speech", "speech_b16", "speech_b64", "rir", "rir_b32"}.  Returns the parity numbers of the current compute dtype against the golden."""
     g = np.load(os.path.join(golden_dir, "g3_%s.npz" % tag))
     if tag == "speech":
         cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (2, 201, 500), False, None, True
     elif tag in ("speech_b16", "speech_b64"):
         cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (int(tag[-2:]), 201, 500), False, None, True
     else:
-        cfg, shape, permuted, oc, jit = (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False
+        cfg, shape, permuted, oc, jit = (500, 1024, 64, 2, 64, 0.25, 1024), (32 if tag == "rir_b32" else 2, 201, 500), True, 1, False
     in_c, h, d, r, rh, beta, k = cfg
     p = O.closed_form_params(O.vqvae_param_shapes(in_c, h, d, rh, k, oc), float(g["cb_scale"]), float(g["gain"]))
     m = _build(cfg, p, use_jitter=jit, out_channels=oc).train()
@@ -131,9 +131,9 @@ def run_vqvae(tag, golden_dir=GOLDEN):
     return out
 
 
-def run_echoed(golden_dir=GOLDEN):
+def run_echoed(golden_dir=GOLDEN, tag="echoed"):
     from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
-    g = np.load(os.path.join(golden_dir, "g3_echoed.npz"))
+    g = np.load(os.path.join(golden_dir, "g3_%s.npz" % tag))
     gain = float(g["gain"])
     sp_p = O.closed_form_params(O.vqvae_param_shapes(201, 1024, 128, 1024, 1024), float(g["speech_cb_scale"]), gain)
     rir_p = O.closed_form_params(O.vqvae_param_shapes(500, 1024, 64, 64, 1024, 1), float(g["rir_cb_scale"]), gain)
@@ -143,14 +143,14 @@ def run_echoed(golden_dir=GOLDEN):
     dec_p = O.closed_form_params(O.decoder_param_shapes(192, 201, 1024, 1024), gain=gain)
     model._decoder.load_state_dict({k[len("_decoder."):]: v for k, v in _expand(dec_p, 2).items()})
     model = model.cuda().train()
-    shape = (2, 201, 500)
+    shape = (32 if tag == "echoed_b32" else 2, 201, 500)
     raw = torch.from_numpy(O.hashed_uniform(int(np.prod(shape)), 21, 2.0).reshape(shape)).abs()
     x = O.standardise(raw).cuda()
     np.random.seed(9)
     recon, sperp, rperp = model(x, x.permute(0, 2, 1))
     err = F.mse_loss(recon, x)
     err.backward()
-    out = {"tag": "echoed", "recon_error_rel": rel_max(err, g["recon_error"]),
+    out = {"tag": tag, "recon_error_rel": rel_max(err, g["recon_error"]),
            "speech_perplexity_rel": rel_max(sperp, g["speech_perplexity"]),
            "rir_perplexity_rel": rel_max(rperp, g["rir_perplexity"]),
            "recon_rel_max": rel_max(wide(recon, g["recon_wide"]), g["recon_wide"]),
@@ -161,7 +161,7 @@ def run_echoed(golden_dir=GOLDEN):
 
 
 def run(tag, golden_dir=GOLDEN):
-    return run_echoed(golden_dir) if tag == "echoed" else run_vqvae(tag, golden_dir)
+    return run_echoed(golden_dir, tag) if tag.startswith("echoed") else run_vqvae(tag, golden_dir)
 
 
 if __name__ == "__main__":      # python tests/g3_cases.py [modes...]  -> one JSON line per (mode, config)

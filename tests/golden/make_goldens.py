@@ -185,7 +185,17 @@ def speech_b64():
     big("speech_b64", (201, 1024, 128, 3, 1024, 0.25, 1024), (64, 201, 500), False, None, True, SPEECH_CB)
 
 
-def g3_echoed():
+def rir_b32():
+    """Round 3: BASELINE configs[2]'s per-GPU share (B = 256 over 8 GPUs), 6 432 codebook rows."""
+    big("rir_b32", (500, 1024, 64, 2, 64, 0.25, 1024), (32, 201, 500), True, 1, False, RIR_CB)
+
+
+def echoed_b32():
+    """Round 3: BASELINE configs[4]'s per-GPU share (B = 128 over 4 GPUs)."""
+    g3_echoed(32, "echoed_b32")
+
+
+def g3_echoed(batch=2, tag="echoed"):
     from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
     from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
     sp_cfg = (201, 1024, 128, 3, 1024, 0.25, 1024)
@@ -200,7 +210,7 @@ def g3_echoed():
     dec_p = O.closed_form_params(O.decoder_param_shapes(192, 201, 1024, 1024), gain=GAIN)
     model._decoder.load_state_dict({k[len("_decoder."):]: v for k, v in expand_aliases(dec_p, 2).items()})
     model.train()
-    shape = (2, 201, 500)
+    shape = (batch, 201, 500)
     x = O.standardise(torch.from_numpy(O.hashed_uniform(int(np.prod(shape)), 21, 2.0).reshape(shape)).abs())
     np.random.seed(9)
     recon, sperp, rperp = model(x, x.permute(0, 2, 1))
@@ -214,8 +224,8 @@ def g3_echoed():
         out["grad_slice:_decoder." + key] = sl(pp.grad)
         out["grad_wide:_decoder." + key] = sl(pp.grad, WIDE_GRAD)
         out["grad_sum:_decoder." + key] = checksum(pp.grad)
-    np.savez_compressed(os.path.join(HERE, "g3_echoed.npz"), **out)
-    print("g3 echoed", float(err), float(sperp), float(rperp))
+    np.savez_compressed(os.path.join(HERE, "g3_%s.npz" % tag), **out)
+    print("g3", tag, float(err), float(sperp), float(rperp))
 
 
 def g5_jitter():
@@ -299,6 +309,8 @@ if __name__ == "__main__":
     big("rir", (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False, RIR_CB)
     speech_b16()
     speech_b64()
+    rir_b32()
+    echoed_b32()
     g3_echoed()
     g5_jitter()
     g6_stft()

@@ -126,6 +126,42 @@ def test_the_bench_workload_against_reference_golden(mode, golden_dir):
         assert r["grad_sum_rel_max"] < 5e-4 and r["encoder_grad_rel_max"] < 1e-2, r
 
 
+@pytest.mark.parametrize("tag", ["rir_b32", "echoed_b32"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16mx", "f16mx_hb", "bf16"], indirect=True)
+def test_rir_and_echoed_at_their_per_gpu_batch_against_reference_golden(mode, tag, golden_dir):
+    """BASELINE configs[2] / [4] at their per-GPU share (B = 32), run by the real reference.  The RIR golden holds 6 432
+    codebook rows of which TWO are reference near-ties of 1.3e-6 and 1.8e-6 relative (11 and 15 fp32 ulps between the two
+    nearest codes).  f32 and bf16x3 return all 6 432 reference indices.  The f16mx family (z within 1.5e-5) returns 6 431: it
+    flips the 1.8e-6 row -- the ONE flipped index in the 47 834 rows of all the goldens (speech B = 2 / 16 / 64, RIR B = 2 / 32),
+    whose other 130 rows with a gap below 1e-4 (down to 4.2e-6) it resolves.  A flipped code is a different decoder input at
+    one position: the reconstruction differs locally (rel-max 6e-2 over ~11 positions, rel-L2 7e-3) and so does the echoed
+    model's, which embeds this RIR encoder.  That is the resolution limit of 3-bit-mantissa cross terms, stated here and
+    in DESIGN section 3 instead of choosing goldens that avoid it; strict users select bf16x3 or f32.
+    The bars below are this golden's measured behaviour, unconditional."""
+    r = run(tag, golden_dir)
+    print("g3-%s %s: %s" % (tag, mode, json.dumps(r)))
+    fx = mode.startswith("f16mx")
+    if tag == "rir_b32":
+        assert r["idx_total"] == 6432
+        if mode == "bf16":
+            assert r["idx_agree"] >= 0.985 and r["mismatch_gap_max"] < 5e-3 and r["z_rel_l2"] < 1.5e-2, r
+        else:
+            assert r["idx_mismatches"] <= (1 if fx else 0) and r["mismatch_gap_max"] < 5e-6, r
+            assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-5 and r["vq_loss_rel"] < 1e-5, r
+    if mode == "bf16":
+        assert r["recon_error_rel"] < 1e-2 and r["recon_rel_l2"] < 0.25 and r["grad_rel_l2_median"] < 0.3, r
+        return
+    assert r["recon_error_rel"] < 5e-5, r
+    if fx:      # one flipped code: local reconstruction difference, gradients of the layers next to it
+        assert r["recon_rel_l2"] < 2e-2 and r["recon_sum_rel"] < 2e-4, r
+        assert r["grad_rel_max"] < 0.15 and r["grad_rel_l2_median"] < 3e-2 and r["grad_sum_rel_max"] < 1e-2, r
+    else:
+        assert r["recon_rel_max"] < 1e-4 and r["recon_sum_rel"] < 1e-5, r
+        assert r["grad_rel_max"] < (5e-3 if mode == "f32" else 3e-2) and r["grad_rel_l2_max"] < (3e-3 if mode == "f32" else 1.5e-2), r
+    if tag == "echoed_b32":
+        assert r["encoders_grad_free"]
+
+
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
 @pytest.mark.parametrize("mode", ["f16mx_hd"], indirect=True)
 def test_half_decoder_mode_default_configs_against_reference_golden(mode, tag, golden_dir):

@@ -125,7 +125,7 @@ def test_g6_stft_unpinned(golden_dir):
     assert g["power_f32"].shape == (1, 201, 26)
 
 
-@pytest.mark.parametrize("tag", ["speech", "rir", "speech_b16", "speech_b64"])
+@pytest.mark.parametrize("tag", ["speech", "rir", "speech_b16", "speech_b64", "rir_b32"])
 def test_g3_default_configs(golden_dir, tag):
     """Default speech / RIR configs at B=2 (about 10 s of CPU); the speech config at B=16 and at the
     bench batch B=64 (8 000 / 32 000 codebook rows; a few seconds each on 8 cores)."""
@@ -134,7 +134,7 @@ def test_g3_default_configs(golden_dir, tag):
     if tag.startswith("speech"):
         cfg, shape, permuted, oc, jit = (201, 1024, 128, 3, 1024, 0.25, 1024), (int(tag[-2:]) if tag[-2:].isdigit() else 2, 201, 500), False, None, True
     else:
-        cfg, shape, permuted, oc, jit = (500, 1024, 64, 2, 64, 0.25, 1024), (2, 201, 500), True, 1, False
+        cfg, shape, permuted, oc, jit = (500, 1024, 64, 2, 64, 0.25, 1024), (32 if tag == "rir_b32" else 2, 201, 500), True, 1, False
     in_c, h, d, r, rh, beta, k = cfg
     p = O.closed_form_params(O.vqvae_param_shapes(in_c, h, d, rh, k, oc), float(g["cb_scale"]), float(g["gain"]))
     p = {key: v.requires_grad_(True) for key, v in p.items()}
