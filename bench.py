@@ -293,8 +293,9 @@ def main():
         keep = ("idx_total", "idx_mismatches", "idx_agree", "mismatch_gap_max", "slice_elems", "z_rel_max", "z_rel_l2", "z_sum_rel",
                 "recon_rel_max", "recon_rel_l2", "recon_sum_rel", "vq_loss_rel", "recon_error_rel", "grad_rel_max",
                 "grad_rel_l2_median", "grad_sum_rel_max", "encoder_grad_rel_max")
-        out = {k: r[k] for k in keep}
-        out["golden"] = "tests/golden/g3_%s.npz (speech ctor, B=%d, made by the reference)" % (tag, int(tag[-2:]) if tag[-2:].isdigit() else 2)
+        out = {k: r[k] for k in keep if k in r}
+        out["golden"] = "tests/golden/g3_%s.npz (%s ctor, B=%d, made by the reference)" % (
+            tag, tag.split("_")[0], int(tag[-2:]) if tag[-2:].isdigit() else 2)
         return out
 
     kind, B = args.config, args.batch
@@ -443,6 +444,13 @@ def main():
             r2, _, _ = run_config(cfgname, other, 32, max(5, min(20, args.steps)), 3, graph=not args.no_graph, timer=False)
             line[key]["throughput_mode" if other == "bf16" else "parity_mode"] = {
                 "dtype": other, "value": r2["value"], "ms_per_step": r2["ms_per_step"], "model_tflops": r2["model_tflops"]}
+            if not args.no_parity:
+                # this config at this batch against the golden the real reference made; for the f16mx family the RIR golden
+                # holds the one index it flips (a 1.8e-6 reference near-tie) -- reported, not hidden
+                pr = parity(args.dtype, cfgname + "_b32")
+                line[key]["parity_b32"] = {k: pr[k] for k in ("idx_total", "idx_mismatches", "mismatch_gap_max", "z_rel_max",
+                                                               "recon_rel_l2", "recon_error_rel", "grad_rel_l2_median", "golden") if k in pr}
+                _ops.set_compute_dtype(args.dtype)
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
