@@ -185,6 +185,37 @@ def speech_b64():
     big("speech_b64", (201, 1024, 128, 3, 1024, 0.25, 1024), (64, 201, 500), False, None, True, SPEECH_CB)
 
 
+def speech_steps():
+    """Round 3: the reference's own loop body (train_speech.py:62-74, 88-91) on the default speech model at B = 16 for six
+    steps -- |x|, per-frame standardise, model(x) with the jitter stream running on from np.random.seed(9), mse + vq loss,
+    backward, torch.optim.Adam(lr=1e-3) -- fresh hashed batches per step.  Stored: per-step losses / perplexities and the
+    parameter checksums afterwards."""
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    cfg = (201, 1024, 128, 3, 1024, 0.25, 1024)
+    p = O.closed_form_params(O.vqvae_param_shapes(201, 1024, 128, 1024, 1024), codebook_scale=SPEECH_CB, gain=GAIN)
+    model = ConvolutionalVQVAE(*cfg)
+    model.load_state_dict(expand_aliases(p, 3))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=False)
+    np.random.seed(9)
+    shape, steps = (16, 201, 500), 6
+    rows = []
+    for s in range(steps):
+        x = O.speech_preprocess(torch.from_numpy(O.hashed_uniform(int(np.prod(shape)), 40 + s, 2.0).reshape(shape)))
+        opt.zero_grad()
+        vq_loss, recon, perp = model(x)
+        recon_error = F.mse_loss(recon, x)
+        (recon_error + vq_loss).backward()
+        opt.step()
+        rows.append([float(recon_error + vq_loss), float(recon_error), float(vq_loss), float(perp)])
+        print("steps", s, rows[-1])
+    out = {"curve": np.array(rows), "cb_scale": np.array(SPEECH_CB), "gain": np.array(GAIN), "batch": np.array(16)}
+    for key, pp in model.named_parameters():
+        out["after_sum:" + key] = checksum(pp)
+        out["after_wide:" + key] = sl(pp, WIDE_GRAD)
+    np.savez_compressed(os.path.join(HERE, "g8_speech_steps.npz"), **out)
+
+
 def rir_b32():
     """Round 3: BASELINE configs[2]'s per-GPU share (B = 256 over 8 GPUs), 6 432 codebook rows."""
     big("rir_b32", (500, 1024, 64, 2, 64, 0.25, 1024), (32, 201, 500), True, 1, False, RIR_CB)
@@ -311,6 +342,7 @@ if __name__ == "__main__":
     speech_b64()
     rir_b32()
     echoed_b32()
+    speech_steps()
     g3_echoed()
     g5_jitter()
     g6_stft()

@@ -195,3 +195,18 @@ def test_g7_location_oracle_reproduces_reference(golden_dir):
             cols = torch.from_numpy((np.arange(L)[None, :] * K + idx).reshape(-1))
             assert rel(p["fc_1.weight"].grad[7, cols], g["full:fc1_grad_row7_touched"]) < 1e-5
             assert int((p["fc_1.weight"].grad.abs().sum(dim=0) != 0).sum()) == int(g["full:fc1_grad_nonzero_cols"])
+
+
+def test_g8_speech_train_steps(golden_dir):
+    """The oracle's trainer against the six reference train steps of the default speech model (B = 16; ~15 s of CPU)."""
+    g = load(golden_dir, "g8_speech_steps.npz")
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    B = int(g["batch"])
+    p = O.closed_form_params(O.vqvae_param_shapes(201, 1024, 128, 1024, 1024), float(g["cb_scale"]), float(g["gain"]))
+    ot = O.OracleTrainer(p, 3, 0.25, use_jitter=True)
+    np.random.seed(9)
+    for s in range(g["curve"].shape[0]):
+        x = O.speech_preprocess(torch.from_numpy(O.hashed_uniform(B * 201 * 500, 40 + s, 2.0).reshape(B, 201, 500)))
+        loss, rec, perp = ot.step(x)
+        assert abs(loss - g["curve"][s, 0]) < 1e-5 * abs(g["curve"][s, 0]), (s, loss, g["curve"][s, 0])
+        assert abs(perp - g["curve"][s, 3]) < 1e-4 * abs(g["curve"][s, 3]), (s, perp)
