@@ -216,6 +216,64 @@ def speech_steps():
     np.savez_compressed(os.path.join(HERE, "g8_speech_steps.npz"), **out)
 
 
+def rir_steps():
+    """Round 3: the loop body of train_rir.py:42-58, 72-75 on the default RIR model (B = 8, four steps): frames standardised
+    over the frequency axis, permuted input, Wiener target standardised and unsqueezed, mse + vq loss, Adam."""
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    cfg = (500, 1024, 64, 2, 64, 0.25, 1024)
+    p = O.closed_form_params(O.vqvae_param_shapes(500, 1024, 64, 64, 1024, 1), codebook_scale=RIR_CB, gain=GAIN)
+    model = ConvolutionalVQVAE(*cfg, use_jitter=False, out_channels=1)
+    model.load_state_dict(expand_aliases(p, 2))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=False)
+    B, rows = 8, []
+    for s in range(4):
+        raw = torch.from_numpy(O.hashed_uniform(B * 201 * 500, 50 + s, 2.0).reshape(B, 201, 500)).abs()
+        wien = torch.from_numpy(O.hashed_uniform(B * 201, 60 + s, 2.0).reshape(B, 201))
+        x, target = O.rir_preprocess(raw, wien)
+        opt.zero_grad()
+        vq_loss, recon, perp = model(x)
+        recon_error = F.mse_loss(recon, target)
+        (recon_error + vq_loss).backward()
+        opt.step()
+        rows.append([float(recon_error + vq_loss), float(recon_error), float(vq_loss), float(perp)])
+        print("rir steps", s, rows[-1])
+    np.savez_compressed(os.path.join(HERE, "g8_rir_steps.npz"), curve=np.array(rows), cb_scale=np.array(RIR_CB),
+                        gain=np.array(GAIN), batch=np.array(B))
+
+
+def echoed_steps():
+    """Round 3: the loop body of train_echoed_speech.py:62-75, 89-92 (B = 4, four steps): two frozen encoders built from the
+    closed-form fills, the decoder trained on the reconstruction error alone, Adam handed every parameter."""
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    from acoustic_locating_vq_vae.vq_vae.echoed_speech_model import EchoedSpeechReconModel
+    sp_p = O.closed_form_params(O.vqvae_param_shapes(201, 1024, 128, 1024, 1024), codebook_scale=SPEECH_CB, gain=GAIN)
+    rir_p = O.closed_form_params(O.vqvae_param_shapes(500, 1024, 64, 64, 1024, 1), codebook_scale=RIR_CB, gain=GAIN)
+    sp = ConvolutionalVQVAE(201, 1024, 128, 3, 1024, 0.25, 1024)
+    sp.load_state_dict(expand_aliases(sp_p, 3))
+    rir = ConvolutionalVQVAE(500, 1024, 64, 2, 64, 0.25, 1024, use_jitter=False, out_channels=1)
+    rir.load_state_dict(expand_aliases(rir_p, 2))
+    model = EchoedSpeechReconModel(rir, sp, 201, 1024, 2, 1024, True)
+    dec_p = O.closed_form_params(O.decoder_param_shapes(192, 201, 1024, 1024), gain=GAIN)
+    model._decoder.load_state_dict({k[len("_decoder."):]: v for k, v in expand_aliases(dec_p, 2).items()})
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=False)
+    np.random.seed(9)
+    B, rows = 4, []
+    for s in range(4):
+        raw = torch.from_numpy(O.hashed_uniform(B * 201 * 500, 70 + s, 2.0).reshape(B, 201, 500)).abs()
+        x = O.standardise(raw)
+        opt.zero_grad()
+        recon, sperp, rperp = model(x, x.permute(0, 2, 1))
+        err = F.mse_loss(recon, x)
+        err.backward()
+        opt.step()
+        rows.append([float(err), float(sperp), float(rperp)])
+        print("echoed steps", s, rows[-1])
+    np.savez_compressed(os.path.join(HERE, "g8_echoed_steps.npz"), curve=np.array(rows), speech_cb_scale=np.array(SPEECH_CB),
+                        rir_cb_scale=np.array(RIR_CB), gain=np.array(GAIN), batch=np.array(B))
+
+
 def rir_b32():
     """Round 3: BASELINE configs[2]'s per-GPU share (B = 256 over 8 GPUs), 6 432 codebook rows."""
     big("rir_b32", (500, 1024, 64, 2, 64, 0.25, 1024), (32, 201, 500), True, 1, False, RIR_CB)
@@ -343,6 +401,8 @@ if __name__ == "__main__":
     rir_b32()
     echoed_b32()
     speech_steps()
+    rir_steps()
+    echoed_steps()
     g3_echoed()
     g5_jitter()
     g6_stft()
