@@ -210,3 +210,19 @@ def test_g8_speech_train_steps(golden_dir):
         loss, rec, perp = ot.step(x)
         assert abs(loss - g["curve"][s, 0]) < 1e-5 * abs(g["curve"][s, 0]), (s, loss, g["curve"][s, 0])
         assert abs(perp - g["curve"][s, 3]) < 1e-4 * abs(g["curve"][s, 3]), (s, perp)
+
+
+def test_g8_rir_train_steps(golden_dir):
+    """The oracle's trainer against the four reference steps of the RIR loop (B = 8)."""
+    g = load(golden_dir, "g8_rir_steps.npz")
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    B = int(g["batch"])
+    p = O.closed_form_params(O.vqvae_param_shapes(500, 1024, 64, 64, 1024, 1), float(g["cb_scale"]), float(g["gain"]))
+    ot = O.OracleTrainer(p, 2, 0.25, use_jitter=False)
+    for s in range(g["curve"].shape[0]):
+        raw = torch.from_numpy(O.hashed_uniform(B * 201 * 500, 50 + s, 2.0).reshape(B, 201, 500)).abs()
+        wien = torch.from_numpy(O.hashed_uniform(B * 201, 60 + s, 2.0).reshape(B, 201))
+        x, target = O.rir_preprocess(raw, wien)
+        loss, rec, perp = ot.step(x, target)
+        assert abs(loss - g["curve"][s, 0]) < 1e-5 * abs(g["curve"][s, 0]), (s, loss, g["curve"][s, 0])
+        assert abs(perp - g["curve"][s, 3]) < 1e-4 * abs(g["curve"][s, 3]), (s, perp)
