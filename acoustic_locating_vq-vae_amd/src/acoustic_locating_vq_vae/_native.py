@@ -744,7 +744,8 @@ def f16mx_range_flag(reset=True, device="cuda"):
 
 def _fmt_serves(t, ref):
     """Can ``t`` be read as an operand of ``ref``'s format?  Same format, or an f16mx tensor read through its H plane."""
-    return (t.planes, t.fmt) == (ref.planes, ref.fmt) or (ref.fmt == "f16" and t.fmt == "f16mx")
+    return (t.planes, t.fmt) == (ref.planes, ref.fmt) or (ref.fmt == "f16" and t.fmt == "f16mx") or \
+        (ref.fmt == "bf16" and t.fmt == "bf16x3")           # ... or a bf16x3 tensor through its hi plane (bf16x3_hb's backward)
 
 
 def _nlc_ptr(t, ref, C, name):
@@ -895,7 +896,8 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     wp, (M, C, KW, wplanes) = packed
     if C != x.C:
         raise RuntimeError("conv1d_bf16: weight expects %d input channels, x has %d" % (C, x.C))
-    if wplanes != (3 if x.fmt in ("f16mx", "f16") else x.planes):       # an f16 launch reads the H image of an f16mx packed weight
+    # an f16 launch reads the H image of an f16mx packed weight, a bf16 launch may read the hi image of a bf16x3 one
+    if wplanes != (3 if x.fmt in ("f16mx", "f16") else x.planes) and not (x.fmt == "bf16" and wplanes == 2):
         raise RuntimeError("conv1d_bf16: weight packed for format %d, activation is %s" % (wplanes, x.fmt))
     split = x.planes == 2
     if bias is not None and bias.numel() != M:
@@ -968,7 +970,7 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
     elif x.fmt == "f16mx":
         family, fn, wsfn = "conv1d_wgrad_f16mx_kernel", lib().alvq_conv1d_wgrad_f16mx, lib().alvq_conv1d_wgrad_f16mx_workspace_bytes
         extra = (_sptr(dy.gscale, 1),)
-    elif x.planes == 2:
+    elif x.planes == 2 and dy.planes == 2:
         family, fn, wsfn = "conv1d_wgrad_bf16x3_kernel", lib().alvq_conv1d_wgrad_bf16x3, lib().alvq_conv1d_wgrad_bf16x3_workspace_bytes
     else:
         family, fn, wsfn = "conv1d_wgrad_bf16_v2_kernel", lib().alvq_conv1d_wgrad_bf16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes

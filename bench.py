@@ -25,6 +25,8 @@ What the line holds (N=1):
                             default-config golden made by the real reference (tests/golden/g3_speech.npz)
   north_star .............. the mode that carries the parity claim (bit-exact indices, 1e-3 forward): its throughput,
                             x CPU, kernel roofline against ITS structural peak, and its parity numbers
+  bf16x3_hb_parity_mode ... the strict alternative: bf16x3 forward (the split format that returns every reference index of every golden)
+                            + one bf16 MFMA per backward product
   f32_parity_mode, bf16x3_parity_mode, script_loop_mode, vq_stress, rir_config, echoed_config ... secondary lines
   cpu_baseline ............ the oracle port timed on the host cores (B=4, BASELINE configs[0])
 """
@@ -53,7 +55,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (N
 # product -> 1 / ((1/3) / 1250 + (2/3) / 2500) = 1875 TFLOP/s for the WHOLE step; each kernel family is judged against the
 # peak of its own arithmetic (FAMILY_PEAK).
 PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0,
-        "f16mx": BF16_MFMA_PEAK_TFLOPS / 2.0, "f16mx_hb": 1875.0, "f16mx_hd": 2200.0}
+        "f16mx": BF16_MFMA_PEAK_TFLOPS / 2.0, "f16mx_hb": 1875.0, "f16mx_hd": 2200.0, "bf16x3_hb": 1500.0}
 FAMILY_PEAK = {"conv1d_f32_kernel": ("f32", F32_MFMA_PEAK_TFLOPS), "conv1d_wgrad_f32_kernel": ("f32", F32_MFMA_PEAK_TFLOPS),
                "conv1d_bf16x3_kernel": ("bf16x3", BF16_MFMA_PEAK_TFLOPS / 3.0), "conv1d_wgrad_bf16x3_kernel": ("bf16x3", BF16_MFMA_PEAK_TFLOPS / 3.0),
                "conv1d_f16mx_kernel": ("f16mx", BF16_MFMA_PEAK_TFLOPS / 2.0), "conv1d_wgrad_f16mx_kernel": ("f16mx", BF16_MFMA_PEAK_TFLOPS / 2.0)}
@@ -61,20 +63,24 @@ PEAK_NOTE = {"f32": "exact-fp32 MFMA peak 157.3 TFLOP/s", "bf16": "dense bf16 (=
              "bf16x3": "2500/3 = 833.3 TFLOP/s algorithmic: three bf16 MFMAs per product",
              "f16mx": "2500/2 = 1250 TFLOP/s algorithmic: one fp16 MFMA + one block-scaled fp8 MFMA of equal duration per product",
              "f16mx_hb": "whole step 1875 TFLOP/s = 1 / ((1/3)/1250 + (2/3)/2500): f16mx forward, one fp16 MFMA per backward product",
+             "bf16x3_hb": "whole step 1500 TFLOP/s = 1 / ((1/3)/833 + (2/3)/2500): bf16x3 forward, one bf16 MFMA per backward product",
              "f16mx_hd": "whole step 2200 TFLOP/s = 1 / (0.136/1250 + 0.864/2500): only the encoder's forward (13.6 of 99.95 GFLOP) at two units"}
 CONV_FAMILIES = {"f32": ("conv1d_f32_kernel", "conv1d_wgrad_f32_kernel"),
                  "bf16": ("conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel", "conv1d_wgrad_bf16_v2_kernel"),
                  "bf16x3": ("conv1d_bf16x3_kernel", "conv1d_wgrad_bf16x3_kernel"),
                  "f16mx": ("conv1d_f16mx_kernel", "conv1d_wgrad_f16mx_kernel"),
                  "f16mx_hb": ("conv1d_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel"),
-                 "f16mx_hd": ("conv1d_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel")}
+                 "f16mx_hd": ("conv1d_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel"),
+                 "bf16x3_hb": ("conv1d_bf16x3_kernel", "conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel",
+                               "conv1d_wgrad_bf16_v2_kernel")}
 MODE_TEXT = {"bf16": "bf16 storage + bf16 MFMA, fp32 accumulate / VQ / losses / master weights",
              "bf16x3": "split-bf16 (hi+lo planes, 3 bf16 MFMAs per product, fp32 accumulate)",
              "f16mx": "fp16 plane + fp8 (hi,lo) plane: one fp16 MFMA + one block-scaled fp8 MFMA per product, fp32 accumulate",
              "f16mx_hb": "f16mx forward (fp32-grade outputs) + fp16 backward (one fp16 MFMA per product under a loss scale, fp32 accumulate)",
              "f16mx_hd": "f16mx encoder + quantiser forward, fp16 decoder forward, fp16 backward (opt-in)",
+             "bf16x3_hb": "bf16x3 forward (three bf16 MFMAs per product) + bf16 backward (one bf16 MFMA per product on the hi planes)",
              "f32": "fp32 storage + exact-fp32 MFMA"}
-PARITY_MODES = ("f16mx_hb", "f16mx", "bf16x3")  # modes whose parity is bit-exact indices / <=1e-3 forward; the fastest carries the claim
+PARITY_MODES = ("f16mx_hb", "bf16x3_hb", "f16mx", "bf16x3")  # modes whose parity is bit-exact indices / <=1e-3 forward; the fastest carries the claim
 SPEECH_CFG = (201, 1024, 128, 3, 1024, 0.25, 1024)          # scripts/train_speech.py:152-153
 RIR_CFG = (500, 1024, 64, 2, 64, 0.25, 1024)                # scripts/train_rir.py:147-149
 
@@ -127,9 +133,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU")
     ap.add_argument("--config", default="speech", choices=["speech", "rir", "echoed"],
                     help="speech = BASELINE configs[1] (the headline); rir = configs[2]; echoed = configs[4]")
-    ap.add_argument("--dtype", default="f16mx_hb", choices=["bf16", "f32", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd"],
+    ap.add_argument("--dtype", default="f16mx_hb", choices=["bf16", "f32", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd", "bf16x3_hb"],
                     help="f16mx_hb (default): the fastest mode that holds the north star's parity -- f16mx forward (fp16 + "
-                         "block-scaled fp8 MFMA per product), fp16 backward; f16mx: the cross terms in the backward too; bf16x3: "
+                         "block-scaled fp8 MFMA per product), fp16 backward; f16mx: the cross terms in the backward too; bf16x3_hb: "
+                         "bf16x3 forward, bf16 backward; bf16x3: "
                          "split-bf16 parity mode (3 bf16 MFMAs per product); f32: exact-fp32 MFMA; bf16: throughput mode (bf16 "
                          "storage/MFMA; ~1 %% of the codebook indices differ)")
     ap.add_argument("--no-secondary", "--no-f32-line", dest="no_secondary", action="store_true",
@@ -336,7 +343,7 @@ def main():
 
     if kind == "speech" and secondary:
         modes = {}
-        for mode in ("f16mx_hb", "f16mx", "bf16x3", "f32", "bf16", "f16mx_hd"):
+        for mode in ("f16mx_hb", "bf16x3_hb", "f16mx", "bf16x3", "f32", "bf16", "f16mx_hd"):
             if mode == args.dtype:
                 modes[mode] = head
                 continue
@@ -345,7 +352,7 @@ def main():
                                            timer=not args.no_kernel_timer)
         if rank == 0:
             for mode, key in (("f32", "f32_parity_mode"), ("bf16x3", "bf16x3_parity_mode"), ("f16mx", "f16mx_parity_mode"),
-                              ("f16mx_hb", "f16mx_hb_parity_mode"), ("bf16", "bf16_throughput_mode"),
+                              ("f16mx_hb", "f16mx_hb_parity_mode"), ("bf16x3_hb", "bf16x3_hb_parity_mode"), ("bf16", "bf16_throughput_mode"),
                               ("f16mx_hd", "f16mx_hd_mode")):
                 if mode != args.dtype:
                     line[key] = {k: v for k, v in modes[mode].items() if k != "kernel_families"}
@@ -353,7 +360,7 @@ def main():
             line["_ns_src"] = (ns_mode, modes[ns_mode])
 
     if rank == 0 and world == 1 and kind == "speech" and not args.no_parity:
-        line["parity"] = {m: parity(m) for m in (["f16mx_hb", "f16mx", "bf16x3", "f32", "bf16", "f16mx_hd"] if secondary else [args.dtype])}
+        line["parity"] = {m: parity(m) for m in (["f16mx_hb", "bf16x3_hb", "f16mx", "bf16x3", "f32", "bf16", "f16mx_hd"] if secondary else [args.dtype])}
         line["parity_b16"] = {args.dtype: parity(args.dtype, "speech_b16")}     # 8 000 rows, smallest top-2 gap 6.9e-6
         line["parity_b64"] = {args.dtype: parity(args.dtype, "speech_b64")}     # the timed workload itself: 32 000 rows, 4.2e-6
         _ops.set_compute_dtype(args.dtype)

@@ -40,7 +40,7 @@ def test_bf16_default_configs_against_reference_golden(mode, tag, golden_dir):
 
 
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
-@pytest.mark.parametrize("mode", ["bf16x3", "f16mx", "f16mx_hb"], indirect=True)
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3_hb", "f16mx", "f16mx_hb"], indirect=True)
 def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_dir):
     """The north star's bar, unconditionally: codebook indices BIT-EXACT (0 of 1000 / 402 differ -- the goldens' smallest
     relative top-2 gap is 3e-5, so there is no near-tie to excuse), outputs within 1e-3 (measured 2e-5) on 4096-element
@@ -68,7 +68,7 @@ def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_
         assert r["encoders_grad_free"]
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd", "bf16"], indirect=True)
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_hb", "f16mx", "f16mx_hb", "f16mx_hd", "bf16"], indirect=True)
 def test_speech_config_at_a_training_batch_against_reference_golden(mode, golden_dir):
     """G3-speech at B = 16 (round 3; made by the real reference): 8 000 codebook rows, 22 of them with a relative top-2
     distance gap below 1e-4 and the smallest at 6.9e-6 -- every parity mode must still return ALL 8 000 indices of the
@@ -93,18 +93,20 @@ def test_speech_config_at_a_training_batch_against_reference_golden(mode, golden
     if mode == "f32":
         assert r["grad_rel_max"] < 3e-3 and r["grad_rel_l2_max"] < 1e-3 and r["grad_sum_rel_max"] < 1e-4, r
     else:
-        assert r["grad_rel_max"] < 5e-2 and r["grad_rel_l2_max"] < 3e-2 and r["grad_rel_l2_median"] < 2e-3, r
-        assert r["grad_sum_rel_max"] < 5e-4 and r["encoder_grad_rel_max"] < 2e-2, r
+        # bf16x3_hb: the backward's bf16 operands (2^-9) set a floor of ~2e-3 under every tensor's rel-L2
+        assert r["grad_rel_max"] < 5e-2 and r["grad_rel_l2_max"] < 3e-2 and r["grad_rel_l2_median"] < (5e-3 if mode == "bf16x3_hb" else 2e-3), r
+        assert r["grad_sum_rel_max"] < (3e-3 if mode == "bf16x3_hb" else 5e-4) and r["encoder_grad_rel_max"] < 2e-2, r
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd", "bf16"], indirect=True)
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_hb", "f16mx", "f16mx_hb", "f16mx_hd", "bf16"], indirect=True)
 def test_the_bench_workload_against_reference_golden(mode, golden_dir):
     """G3-speech at B = 64: BASELINE configs[1] itself -- the batch bench.py times -- run by the real reference on the CPU
     (tests/golden/g3_speech_b64.npz: 32 000 codebook rows, 92 of them with a relative top-2 gap below 1e-4, the smallest
     4.2e-6).  Every parity mode must return ALL 32 000 reference indices, outputs at the north star's bar, and gradients at
     the level a training batch gives (a flipped ReLU gate is one of 32 000 terms).
     Measured: f32 0 / 32000, z 1.5e-6, grads max-norm 1.7e-3; bf16x3 0, 6.6e-6, 6.2e-3; f16mx = f16mx_hb 0, 1.8e-5, recon
-    1.9e-5, grads 5.0e-3 / 4.4e-3 (rel-L2 median 1.3e-4 / 3.6e-4); f16mx_hd recon 6.2e-4, grads 2.3e-2; bf16 264 differ."""
+    1.9e-5, grads 5.0e-3 / 4.4e-3 (rel-L2 median 1.3e-4 / 3.6e-4); bf16x3_hb = bf16x3's forward, grads 6.3e-3 (median 1.9e-3: bf16
+    operands in the backward); f16mx_hd recon 6.2e-4, grads 2.3e-2; bf16 264 differ."""
     r = run("speech_b64", golden_dir)
     print("g3-speech_b64 %s: %s" % (mode, json.dumps(r)))
     assert r["idx_total"] == 32000 and r["slice_elems"] >= 4096
@@ -122,12 +124,12 @@ def test_the_bench_workload_against_reference_golden(mode, golden_dir):
     if mode == "f32":
         assert r["grad_rel_max"] < 5e-3 and r["grad_rel_l2_max"] < 1e-3 and r["grad_sum_rel_max"] < 1e-4, r
     else:
-        assert r["grad_rel_max"] < 2e-2 and r["grad_rel_l2_max"] < 1.5e-2 and r["grad_rel_l2_median"] < 1e-3, r
-        assert r["grad_sum_rel_max"] < 5e-4 and r["encoder_grad_rel_max"] < 1e-2, r
+        assert r["grad_rel_max"] < 2e-2 and r["grad_rel_l2_max"] < 1.5e-2 and r["grad_rel_l2_median"] < (5e-3 if mode == "bf16x3_hb" else 1e-3), r
+        assert r["grad_sum_rel_max"] < (3e-3 if mode == "bf16x3_hb" else 5e-4) and r["encoder_grad_rel_max"] < 1e-2, r
 
 
 @pytest.mark.parametrize("tag", ["rir_b32", "echoed_b32"])
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16mx", "f16mx_hb", "bf16"], indirect=True)
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_hb", "f16mx", "f16mx_hb", "bf16"], indirect=True)
 def test_rir_and_echoed_at_their_per_gpu_batch_against_reference_golden(mode, tag, golden_dir):
     """BASELINE configs[2] / [4] at their per-GPU share (B = 32), run by the real reference.  The RIR golden holds 6 432
     codebook rows of which TWO are reference near-ties of 1.3e-6 and 1.8e-6 relative (11 and 15 fp32 ulps between the two
