@@ -27,10 +27,11 @@ Two precisions share these chains through a small "engine" object:
   4.3e-4) -- in both modes the gradient error is set by the ~1e-5 forward noise flipping ReLU gates, not by the backward
   products -- at 0.72x the f16mx step time.
 
-* ``bf16x3_hb`` -- bf16x3 forward + bf16 ("half") backward: the forward is bf16x3's bit for bit -- the strictest split format:
-  6e-6, and every one of the 47 834 codebook rows of the reference goldens comes back with the reference's index, including
-  the 1.8e-6 near-tie the f16mx family flips -- and every backward product is ONE bf16 MFMA on the hi planes (no loss
-  scale: bf16 has fp32's range).  Gradient rel-L2 ~2e-3 per tensor (the bf16 operands), 0.94x f16mx_hb's rate.
+* ``bf16x3_hb`` -- bf16x3 forward + bf16 ("half") backward: the forward is bf16x3's bit for bit -- the most accurate split
+  format: 6e-6, i.e. 2.3x fewer flipped near-ties than the f16mx family (expected 14 against 33 per million codebook rows,
+  tools/near_ties.py; none in the 47 834 rows of the reference goldens, where f16mx flips one) -- and every backward product
+  is ONE bf16 MFMA on the hi planes (no loss scale: bf16 has fp32's range).  Gradient rel-L2 ~2e-3 per tensor (the bf16
+  operands), 0.94x f16mx_hb's rate.
 
 * ``f16mx_hd`` -- (opt-in) f16mx_hb with the DECODER's forward on fp16 operands too (one fp16 plane per activation, one fp16
   MFMA per product; the H image of the same packed weights).  Encoder, pre-VQ convolution and quantiser are f16mx_hb's bit
@@ -471,8 +472,8 @@ class _F16MXHBEngine(_F16MXEngine):
 
 
 class _BF16x3HBEngine(_BF16x3Engine):
-    """bf16x3 forward, bf16 ("half") backward -- f16mx_hb's idea on the strictest split format: the forward is bf16x3's bit for
-    bit (6e-6; the one split mode that returns every reference index of every golden), gradients enter
+    """bf16x3 forward, bf16 ("half") backward -- f16mx_hb's idea on the most accurate split format: the forward is bf16x3's bit
+    for bit (6e-6: 2.3x fewer flipped near-ties than f16mx, none in the goldens' 47 834 rows), gradients enter
     their chains as ONE bf16 plane (fp32 range: no loss scale) and every backward product is one bf16 MFMA on the hi planes
     of the saved activations / packed weights."""
     name = "bf16x3_hb"

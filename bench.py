@@ -25,7 +25,7 @@ What the line holds (N=1):
                             default-config golden made by the real reference (tests/golden/g3_speech.npz)
   north_star .............. the mode that carries the parity claim (bit-exact indices, 1e-3 forward): its throughput,
                             x CPU, kernel roofline against ITS structural peak, and its parity numbers
-  bf16x3_hb_parity_mode ... the strict alternative: bf16x3 forward (the split format that returns every reference index of every golden)
+  bf16x3_hb_parity_mode ... the stricter alternative: bf16x3 forward (6e-6: 2.3x fewer flipped near-ties than f16mx, none in the goldens)
                             + one bf16 MFMA per backward product
   f32_parity_mode, bf16x3_parity_mode, script_loop_mode, vq_stress, rir_config, echoed_config ... secondary lines
   cpu_baseline ............ the oracle port timed on the host cores (B=4, BASELINE configs[0])

@@ -1,5 +1,5 @@
 """bf16x3_hb mode: bf16x3 forward + bf16 backward on the hi planes.  The forward must be bf16x3's BIT FOR BIT (same kernels,
-same operands) -- it is the split format that returns every reference index of every golden -- and the gradients carry the
+same operands) -- the most accurate split format: no flipped index in the goldens' 47 834 rows -- and the gradients carry the
 rounding of bf16 operands (2^-9 per operand) under an exact forward: rel-L2 ~2e-3 per tensor, between f16mx_hb's 5e-4 and the
 bf16 mode's 0.1 (whose error is its FORWARD's, flipped gates and codes)."""
 import numpy as np
