@@ -102,10 +102,10 @@ def test_two_ranks_on_one_card_gloo():
     assert finals["1"] == finals["2"], finals            # same arithmetic whichever way the buffer is reduced
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-6), ("f16mx_hb", 2e-5)])
+@pytest.mark.parametrize("mode,tol,ranks", [("f32", 2e-6, 2), ("f16mx_hb", 2e-5, 2), ("f32", 2e-6, 4)])
 @pytest.mark.parametrize("buckets", [1, 2])
-def test_two_rank_steps_equal_one_rank_on_the_concatenated_batch(mode, tol, buckets, tmp_path):
-    """Data parallelism through the real HIP path: two ranks (sharing the card over gloo), each on its half of a batch of 8,
+def test_two_rank_steps_equal_one_rank_on_the_concatenated_batch(mode, tol, ranks, buckets, tmp_path):
+    """Data parallelism through the real HIP path: two (or four) ranks (sharing the card over gloo), each on its share of a batch of 8,
     must end three train steps on the parameters ONE process reaches on the whole batch -- the flat buffer is summed once per
     step, the 1/world factor lives in the Adam launch, local means of equal shards average to the global mean.  Measured:
     f32 losses 7e-8, parameters within 3e-6 (fp32 summation order); f16mx_hb losses 2e-7, parameters within 1e-4 with 0.04 % of
@@ -115,7 +115,7 @@ def test_two_rank_steps_equal_one_rank_on_the_concatenated_batch(mode, tol, buck
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
     p = subprocess.run([sys.executable, helper, mode, one, str(buckets)], env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), helper, mode, two, str(buckets)]
     p = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -123,7 +123,7 @@ def test_two_rank_steps_equal_one_rank_on_the_concatenated_batch(mode, tol, buck
     dl = float((a["losses"] - b["losses"]).abs().max() / a["losses"].abs().max())
     moved = (a["flat"] - b["flat"]).abs()
     frac = float((moved > 1e-5).float().mean())
-    print("%s buckets %d: losses rel %.2e, parameters max |diff| %.2e, fraction beyond 1e-5: %.2e" % (mode, buckets, dl, float(moved.max()), frac))
+    print("%s ranks %d buckets %d: losses rel %.2e, parameters max |diff| %.2e, fraction beyond 1e-5: %.2e" % (mode, ranks, buckets, dl, float(moved.max()), frac))
     assert dl < tol
     # Adam moves an entry by ~lr per step whatever the gradient's size: an entry whose gradient is rounding noise on one side can
     # differ by a full step; the statement is about how FEW do (f32: none)
