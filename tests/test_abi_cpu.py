@@ -81,3 +81,22 @@ def test_wgrad_workspace_covers_every_segment_count(native):
     assert lib.alvq_conv1d_wgrad_f16mx_splits(5, 128, 1024, 500, 1, 3) == 60   # the advisor's case: needs 60 ...
     assert lib.alvq_conv1d_wgrad_f16mx_workspace_bytes(5, 128, 1024, 500, 1) >= 60 * 1024 * 128 * 4   # ... and gets them
     assert lib.alvq_conv1d_wgrad_f16mx_splits(5, 128, 1024, 500, 1, 5) == -1
+
+
+def test_every_entry_point_rejects_null_arguments_before_any_launch(native):
+    """The error convention of the boundary: every entry point validates its arguments BEFORE any launch and
+    returns a negative status with a message -- called here with null pointers and zero sizes on a machine without a GPU:
+    no crash, no HIP error (a launch attempt would return a positive hipError_t), a message from the library."""
+    import ctypes
+    lib = native.lib()
+    checked = 0
+    for name, (res, args) in native._SIGNATURES.items():
+        if res is not native._i32 or not any(a is ctypes.c_void_p for a in args):
+            continue
+        vals = [0.0 if a in (ctypes.c_float, ctypes.c_double) else (0 if a in (ctypes.c_int, ctypes.c_int64) else None) for a in args]
+        rc = getattr(lib, name)(*vals)
+        msg = lib.alvq_last_error() or b""
+        assert rc < 0, (name, rc)
+        assert msg.startswith(b"alvq_"), (name, msg)
+        checked += 1
+    assert checked >= 55, checked
