@@ -265,20 +265,21 @@ extern "C" int alvq_relu_mask_bf16(const void* dy, const void* t, void* out, int
 static int conv1d_16bit(int elem, const float* out_scale, const void* x, const void* wp, const float* bias, const void* skip1,
                         const void* skip2, const void* mask, const void* post, void* y, void* y2, float* y_ncl, int B, int C, int M,
                         int L, int KW, int relu, const void* mask_bits, void* relu_bits_out, void* stream) {
-  ALVQ_REQUIRE(x && wp && (y || y_ncl), ALVQ_EINVAL, "alvq_conv1d_bf16: null x/wp/y");
-  ALVQ_REQUIRE(!(y && y_ncl), ALVQ_EINVAL, "alvq_conv1d_bf16: choose one of y (NLC bf16) and y_ncl (NCL fp32)");
-  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "alvq_conv1d_bf16: bad dims");
-  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16: KW=%d (only 1 and 3)", KW);
-  ALVQ_REQUIRE((y2 == nullptr) == (post == nullptr), ALVQ_EINVAL, "alvq_conv1d_bf16: y2 and post go together");
+  const char* const who = elem ? "alvq_conv1d_f16" : "alvq_conv1d_bf16";
+  ALVQ_REQUIRE(x && wp && (y || y_ncl), ALVQ_EINVAL, "%s: null x/wp/y", who);
+  ALVQ_REQUIRE(!(y && y_ncl), ALVQ_EINVAL, "%s: choose one of y (NLC) and y_ncl (NCL fp32)", who);
+  ALVQ_REQUIRE(B > 0 && C > 0 && M > 0 && L > 0, ALVQ_EINVAL, "%s: bad dims", who);
+  ALVQ_REQUIRE(KW == 1 || KW == 3, ALVQ_EUNSUPPORTED, "%s: KW=%d (only 1 and 3)", who, KW);
+  ALVQ_REQUIRE((y2 == nullptr) == (post == nullptr), ALVQ_EINVAL, "%s: y2 and post go together", who);
   ALVQ_REQUIRE(!y_ncl || (!skip1 && !skip2 && !mask && !post && !relu), ALVQ_EUNSUPPORTED,
-               "alvq_conv1d_bf16: the NCL fp32 epilogue fuses bias only");
-  ALVQ_REQUIRE((long)B * (L + 1) < (1L << 30), ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16: problem too large");
+               "%s: the NCL fp32 epilogue fuses bias only", who);
+  ALVQ_REQUIRE((long)B * (L + 1) < (1L << 30), ALVQ_EUNSUPPORTED, "%s: problem too large", who);
   ConvBArgs a{(const u16*)x, (const u16*)wp, bias, (const u16*)skip1, (const u16*)skip2, (const u16*)mask, (const u16*)post,
               (u16*)y, (u16*)y2, y_ncl, B, L, pad_to(C, TB_K), M, pad_to(M, TB_K), pad_to(M, WP_ROWS), relu,
               (int)(alvq_nlc_rows(B, L) / TB_R), pad_to(M, TB_M) / TB_M, (const unsigned char*)mask_bits,
               (unsigned char*)relu_bits_out};
-  ALVQ_REQUIRE(!(mask && mask_bits), ALVQ_EINVAL, "alvq_conv1d_bf16: pass the mask as a tensor or as bits, not both");
-  ALVQ_REQUIRE(!y_ncl || (!mask_bits && !relu_bits_out), ALVQ_EUNSUPPORTED, "alvq_conv1d_bf16: sign bits go with the NLC output");
+  ALVQ_REQUIRE(!(mask && mask_bits), ALVQ_EINVAL, "%s: pass the mask as a tensor or as bits, not both", who);
+  ALVQ_REQUIRE(!y_ncl || (!mask_bits && !relu_bits_out), ALVQ_EUNSUPPORTED, "%s: sign bits go with the NLC output", who);
   hipStream_t s = (hipStream_t)stream;
   a.relu = relu ? 1 : 0;
   a.elem = elem;
