@@ -71,3 +71,27 @@ def test_trainer_steps_eager_and_replayed_track_bf16x3():
     assert np.isfinite(losses["bf16x3_hb", True]).all()
     assert losses["bf16x3_hb", True] == losses["bf16x3_hb", False]
     np.testing.assert_allclose(losses["bf16x3_hb", True], losses["bf16x3", True], rtol=5e-3)
+
+
+@pytest.fixture
+def wide_min_tiles(request):
+    from acoustic_locating_vq_vae import _native as N
+    prev = N.set_option("wide_min_tiles", request.param)
+    yield request.param
+    N.set_option("wide_min_tiles", prev)
+
+
+@pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
+@pytest.mark.parametrize("wide_min_tiles", [192, 1], ids=["default_dispatch", "wide_forced"], indirect=True)
+def test_default_configs_against_reference_golden_under_both_dispatches(tag, wide_min_tiles, golden_dir):
+    """The B = 2 goldens under the dispatch a user gets (the bf16 backward then runs the 128 x 128 kernels, reading the hi
+    planes of bf16x3 activations as operands and masks) and under the forced 256 x 256 kernels: same bars."""
+    import json
+    from g3_cases import run
+    _ops.set_compute_dtype("bf16x3_hb")
+    r = run(tag, golden_dir)
+    print("g3-%s bf16x3_hb wide_min_tiles=%d: %s" % (tag, wide_min_tiles, json.dumps(r)))
+    if tag != "echoed":
+        assert r["idx_mismatches"] == 0 and r["z_rel_max"] < 1e-4 and r["vq_loss_rel"] < 1e-5, r
+    assert r["recon_error_rel"] < 1e-5 and r["recon_rel_max"] < 1e-3 and r["recon_sum_rel"] < 1e-5, r
+    assert r["grad_rel_max"] < 0.1 and r["grad_rel_l2_max"] < 1.5e-2 and r["grad_rel_l2_median"] < 5e-3 and r["grad_sum_rel_max"] < 3e-3, r
