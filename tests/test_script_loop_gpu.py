@@ -89,7 +89,7 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16x3", 2e-3), ("f16mx", 2e-3)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16x3", 2e-3), ("f16mx", 2e-3), ("f16mx_hb", 2e-3), ("bf16x3_hb", 4e-3)])
 def test_speech_script_loop_tracks_the_cpu_reference_path(dtype, tol):
     from acoustic_locating_vq_vae import _ops
     cfg = (20, 48, 8, 2, 24, 0.25, 64)          # in, H, D, R, RH, beta, K
@@ -106,9 +106,13 @@ def test_speech_script_loop_tracks_the_cpu_reference_path(dtype, tol):
         got = speech_loop(m, m.parameters(), [x.cuda() for x in x_raw], steps, jitter_seed=11)
     finally:
         _ops.set_compute_dtype(prev)
+    print(dtype, "got", got, "want", want)
     for g, w in zip(got, want):
-        for a, b in zip(g, w):
-            assert abs(a - b) <= tol * max(abs(b), 1e-3), (got, want)
+        for i, (a, b) in enumerate(zip(g, w)):
+            # the perplexity of 99 rows over 64 codes moves by 2 % when ONE row changes its code: the modes with a reduced-
+            # precision backward (weights drift by their gradient noise) get that much room on it, not on the losses
+            t = 2.5e-2 if (i == 2 and dtype.endswith("_hb")) else tol
+            assert abs(a - b) <= t * max(abs(b), 1e-3), (got, want)
     sd = m.state_dict()
     for k, v in p_cpu.items():
         assert rel(sd[k], v.detach()) < 10 * tol, k
