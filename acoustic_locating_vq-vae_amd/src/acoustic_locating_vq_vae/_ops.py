@@ -23,13 +23,13 @@ Two precisions share these chains through a small "engine" object:
 
 * ``f16mx_hb`` -- f16mx forward + fp16 ("half") backward: the forward is f16mx's bit for bit; every backward product is
   one fp16 MFMA on the H planes of the saved activations / packed weights and of gradients kept as ONE fp16 plane under the
-  loss scale.  Measured against f32 at the speech config (tools/gate_flips.py): gradient rel-L2 4.8e-4 median (f16mx:
+  loss scale.  Measured against f32 at the speech config (tests/analysis/gate_flips.py): gradient rel-L2 4.8e-4 median (f16mx:
   4.3e-4) -- in both modes the gradient error is set by the ~1e-5 forward noise flipping ReLU gates, not by the backward
   products -- at 0.72x the f16mx step time.
 
 * ``bf16x3_hb`` -- bf16x3 forward + bf16 ("half") backward: the forward is bf16x3's bit for bit -- the most accurate split
   format: 6e-6, i.e. 2.3x fewer flipped near-ties than the f16mx family (expected 14 against 33 per million codebook rows,
-  tools/near_ties.py; none in the 47 834 rows of the reference goldens, where f16mx flips one) -- and every backward product
+  tests/analysis/near_ties.py; none in the 47 834 rows of the reference goldens, where f16mx flips one) -- and every backward product
   is ONE bf16 MFMA on the hi planes (no loss scale: bf16 has fp32's range).  Gradient rel-L2 ~2e-3 per tensor (the bf16
   operands), 0.94x f16mx_hb's rate.
 
@@ -515,7 +515,7 @@ def _engine(name=None, role=None):
     return _ROLE_ENGINES.get((_DTYPE, role), _ENGINES[_DTYPE])()
 
 
-_ACT_TAP = None     # analysis hook (tools/gate_flips.py): a list that receives (engine name, saved activations) per node
+_ACT_TAP = None     # analysis hook (tests/analysis/gate_flips.py): a list that receives (engine name, saved activations) per node
 
 
 def _save(ctx, eng, tensors, acts):

@@ -9,13 +9,13 @@ element it feeds fully on or off.  This tool measures, at the speech config with
   * the gradient error of the split mode against the f32 mode, per batch size -- a flipped gate is one term in B*L,
     so the max-norm error must fall roughly as 1/sqrt(B) while the flip RATE stays constant.
 
-    python3 tools/gate_flips.py [modes ...]      (GPU box; prints one JSON line per (mode, batch))
+    python3 tests/analysis/gate_flips.py [modes ...]      (GPU box; prints one JSON line per (mode, batch))
 """
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.join(ROOT, "acoustic_locating_vq-vae_amd")
 for p in (ROOT, PKG, os.path.join(PKG, "src"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)

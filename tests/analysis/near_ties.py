@@ -3,11 +3,11 @@ its two smallest distances exceeds the reference's own gap between them.  This t
 (32 000 rows), per mode: e = [(d(i2) - d(i1)) in the mode - the same in fp64 from the f32-mode latent] / d(i1) per row, with
 (i1, i2) the two nearest codes, and combines mean|e| with the golden's density of near-ties rho (P(gap < g) ~ rho * g, counted
 from the reference's stored top-2 distances) into the expected flips per million rows, rho * mean|e| / 2.
-    python tools/near_ties.py [modes...]"""
+    python tests/analysis/near_ties.py [modes...]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.join(ROOT, "acoustic_locating_vq-vae_amd")
 for p in (ROOT, PKG, os.path.join(PKG, "src"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)

@@ -176,7 +176,7 @@ def big(tag, cfg, shape, permuted, out_channels, use_jitter, cb_scale):
 def speech_b16():
     """Round 3: the speech config at a training-like batch (8000 codebook rows).  At B = 2 a flipped ReLU gate is one of 1000
     terms of a weight-gradient element; this golden shows the split modes' gradient agreement where the batch averages the
-    flips down (tools/gate_flips.py predicts ~1/sqrt(B)) -- and eight times as many indices that must all be bit-exact."""
+    flips down (tests/analysis/gate_flips.py predicts ~1/sqrt(B)) -- and eight times as many indices that must all be bit-exact."""
     big("speech_b16", (201, 1024, 128, 3, 1024, 0.25, 1024), (16, 201, 500), False, None, True, SPEECH_CB)
 
 

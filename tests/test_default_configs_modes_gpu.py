@@ -59,7 +59,7 @@ def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_
     # Gradients (outside the north star's wording; stated separately in DESIGN section 6).  The ~1e-5 forward noise flips
     # a few dozen of the ~1e7 ReLU gates (pre-activations within rounding of zero) and a flipped gate is a full-size
     # error in ONE of the B * L = 1000 (402) terms of a weight-gradient element: ~1/sqrt(1000) of that element at these
-    # B = 2 goldens, shrinking with the batch (tools/gate_flips.py measures both).  Measured on the 2048-element slices:
+    # B = 2 goldens, shrinking with the batch (tests/analysis/gate_flips.py measures both).  Measured on the 2048-element slices:
     # max-norm 1.5e-2 ... 6e-2, per-tensor rel-L2 <= 8e-3 (median 3e-4 ... 2.6e-3), whole-tensor checksums <= 1.4e-3.
     # Strict gradient parity (1e-4 max-norm here) is the f32 mode's, tests/test_modules_gpu.py.
     assert r["grad_rel_max"] < 0.1 and r["encoder_grad_rel_max"] < 0.1, r
@@ -73,7 +73,7 @@ def test_speech_config_at_a_training_batch_against_reference_golden(mode, golden
     """G3-speech at B = 16 (round 3; made by the real reference): 8 000 codebook rows, 22 of them with a relative top-2
     distance gap below 1e-4 and the smallest at 6.9e-6 -- every parity mode must still return ALL 8 000 indices of the
     reference -- and gradients where a flipped ReLU gate is one of 8 000 terms instead of one of 1 000: the split modes'
-    max-norm error falls from 4e-2 (B = 2) to 1e-2, as tools/gate_flips.py's 1/sqrt(B) says.
+    max-norm error falls from 4e-2 (B = 2) to 1e-2, as tests/analysis/gate_flips.py's 1/sqrt(B) says.
     Measured: f32 0 / 8000, z 1.6e-6, grads 9.8e-4; bf16x3 0, 7e-6, 2.7e-2 (rel-L2 median 1.4e-4); f16mx = f16mx_hb 0, 1.5e-5,
     recon 2.3e-5, grads 1.0e-2 (median 1.6e-4 / 5.9e-4); f16mx_hd recon 6.7e-4; bf16 68 differ (99.15 %)."""
     r = run("speech_b16", golden_dir)
