@@ -24,10 +24,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-result", "-I", os.path.join(os.path.dirname(HERE), "include")]
 
 
-def _stamp(path):
+def _stamp(path, only=None):
+    """Hash of every header + (all sources | the one source ``only``) + the flags."""
     h = hashlib.sha1()
     for f in sorted(os.listdir(CSRC)) + ["../../include/alvq.h"]:
-        if f.endswith((".h", ".hip")):
+        if f.endswith(".h") or (f.endswith(".hip") and (only is None or f == only)):
             with open(os.path.join(CSRC, f), "rb") as fh:
                 h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
@@ -48,11 +49,17 @@ def build(force=False, verbose=True, debug_kernels=False):
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
     def cc(src):
+        # per-object stamp: an edit to one .hip recompiles that file only (a header edit recompiles everything)
         obj = os.path.join(obj_dir, src[:-4] + ".o")
+        ostamp_file, ostamp = obj + ".stamp", _stamp(CSRC, only=src) + " ".join(flags)
+        if not force and os.path.exists(obj) and os.path.exists(ostamp_file) and open(ostamp_file).read() == ostamp:
+            return obj
         cmd = [HIPCC] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(ostamp_file, "w") as fh:
+            fh.write(ostamp)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:

@@ -61,6 +61,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
+// defined in conv1d_f16mx.hip: device addresses (current device) of the fp16-range formats' range flag -- the bits raised
+// since the last guarded alvq_adam_advance_f32 / since it was read -- and of the sticky word the former are folded into
+int* fx_range_flag_ptr();
+int* fx_range_sticky_ptr();
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -123,8 +123,6 @@ __device__ __forceinline__ bool fp16_limit_reached(unsigned run) { return (run &
 __device__ __forceinline__ void fp16_report(unsigned run, int* flag) {
   if (flag && __any(fp16_limit_reached(run)) && (threadIdx.x & 63) == 0) atomicOr(flag, 4);
 }
-// defined in conv1d_f16mx.hip: device address of the format's sticky range flag on the current device
-int* fx_range_flag_ptr();
 
 // defined in conv1d_bf16_v2.hip: the 256x256-tile kernel for wide layers
 int conv1d_bf16_v2_launch(const ConvBArgs& a, int KW, hipStream_t stream);

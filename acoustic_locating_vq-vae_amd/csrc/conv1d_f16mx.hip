@@ -500,7 +500,12 @@ __global__ __launch_bounds__(512, 2) void conv1d_f16mx_kernel(ConvFxArgs ax) {
 // conversion INTO the format (model inputs, gradients entering a backward chain); bit 2 = a value PRODUCED inside a chain
 // (an activation, or a loss-scaled gradient that outgrew the 2^8 headroom) reached the limit or is a NaN -- watched by
 // the epilogues of the f16mx and fp16 convolutions.  Read / cleared by alvq_f16mx_range_flag.
+// Round 4: the flag has two words.  g_fx_range_flag collects the bits raised since the last GUARDED optimiser advance
+// (alvq_adam_advance_f32 with a skip slot: the start of a Trainer step), so that a step's last launch can turn "did THIS
+// step saturate" into the skip slot of the flat gradient buffer (alvq_range_flag_to_slot); the advance folds the bits into
+// g_fx_range_sticky.  alvq_f16mx_range_flag reports / clears the union.
 __device__ int g_fx_range_flag = 0;
+__device__ int g_fx_range_sticky = 0;
 
 int* fx_range_flag_ptr() {
   static int* cache[64] = {};
@@ -513,9 +518,20 @@ int* fx_range_flag_ptr() {
   return cache[d];
 }
 
+int* fx_range_sticky_ptr() {
+  static int* cache[64] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+  if (!cache[d]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fx_range_sticky)) == hipSuccess) cache[d] = (int*)p;
+  }
+  return cache[d];
+}
+
 __global__ void fx_range_flag_kernel(int* out, int reset) {
-  *out = g_fx_range_flag;
-  if (reset) g_fx_range_flag = 0;
+  *out = g_fx_range_flag | g_fx_range_sticky;
+  if (reset) { g_fx_range_flag = 0; g_fx_range_sticky = 0; }
 }
 
 // (B,C,L) fp32 -> f16mx NLC planes, optionally multiplied by a device scalar (the loss scale of a backward chain)

@@ -189,8 +189,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 
 // Same arithmetic with the step-dependent scalars read from device memory, so a captured hipGraph can be
 // replayed every step: sc = {lr/bias_correction1, sqrt(bias_correction2), grad_scale}.
+// ``skip`` (nullable): a device float; non-zero = this step's values saturated an fp16-range format on some rank (the
+// slot travels through the step's all-reduce inside the flat gradient buffer) -- the update is NOT applied: parameters and
+// moments stay bit for bit what they were (the dynamic-loss-scaling "skip" pattern, no host sync).
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g, float* m, float* v, long n, const float* sc,
-                                                       float beta1, float beta2, float eps) {
+                                                       float beta1, float beta2, float eps, const float* skip) {
+  if (skip && *skip != 0.f) return;
   const float lr_bc1 = sc[0], bc2_sqrt = sc[1], gscale = sc[2];
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
     const float gr = g[e] * gscale;
@@ -206,14 +210,31 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* p, const float* g,
 // Advance the device-side step counter and derive that step's scalars from it (double arithmetic, as the host
 // would): sc = {lr/(1-beta1^t), sqrt(1-beta2^t), grad_scale, t}.  No host buffer is involved, so nothing races when
 // the host queues many steps ahead of the device, and the launch can be replayed from a graph.
-__global__ void adam_advance_kernel(float* sc, double lr, double beta1, double beta2, double grad_scale) {
+// Guarded form (``prev_skip`` non-null: the skip slot of the flat gradient buffer, still holding the PREVIOUS step's
+// verdict because the buffer is zeroed inside the step's body): a skipped step does not count -- t stays where it was,
+// sc[4] (skipped steps since the counter was last read) goes up by one -- and the range flag's bits of everything that
+// ran since the last step (evaluation passes, the previous step itself) move into the sticky word, so that the step about
+// to run sees only its own.
+__global__ void adam_advance_kernel(float* sc, double lr, double beta1, double beta2, double grad_scale, const float* prev_skip,
+                                    int* range_flag, int* range_sticky) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double t = (double)sc[3] + 1.0;
+  double t = (double)sc[3];
+  if (prev_skip && *prev_skip != 0.f) sc[4] += 1.f;
+  else t += 1.0;
+  if (prev_skip && range_flag) {
+    const int f = *range_flag;
+    if (f) { *range_sticky |= f; *range_flag = 0; }
+  }
+  if (t < 1.0) t = 1.0;                       // the very first step was skipped: its scalars are still step 1's
   sc[0] = (float)(lr / (1.0 - pow(beta1, t)));
   sc[1] = (float)sqrt(1.0 - pow(beta2, t));
   sc[2] = (float)grad_scale;
   sc[3] = (float)t;
 }
+
+// slot = 1 if the range flag holds any bit (set since the step's alvq_adam_advance_f32 cleared it), else 0: the last
+// launch of a step's backward; the slot is then summed over the ranks with the gradients
+__global__ void range_flag_to_slot_kernel(float* slot, const int* range_flag) { *slot = *range_flag ? 1.f : 0.f; }
 
 
 // y[r] = mean_l x[r][l] (one wave per row; fixed-order sum: lane partials over l = lane, lane + 64, ... then the butterfly)
@@ -341,16 +362,29 @@ extern "C" int alvq_adam_f32(float* param, const float* grad, float* exp_avg, fl
 }
 
 extern "C" int alvq_adam_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                 const float* scalars, float beta1, float beta2, float eps, void* stream) {
+                                 const float* scalars, float beta1, float beta2, float eps, const float* skip, void* stream) {
   ALVQ_REQUIRE(param && grad && exp_avg && exp_avg_sq && scalars, ALVQ_EINVAL, "alvq_adam_dev_f32: null pointer");
   ALVQ_REQUIRE(n > 0, ALVQ_EINVAL, "alvq_adam_dev_f32: n <= 0");
   hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
-                     (long)n, scalars, beta1, beta2, eps);
+                     (long)n, scalars, beta1, beta2, eps, skip);
   return check_launch("alvq_adam_dev_f32");
 }
 
-extern "C" int alvq_adam_advance_f32(float* scalars, double lr, double beta1, double beta2, double grad_scale, void* stream) {
+extern "C" int alvq_adam_advance_f32(float* scalars, double lr, double beta1, double beta2, double grad_scale,
+                                     const float* prev_skip, void* stream) {
   ALVQ_REQUIRE(scalars, ALVQ_EINVAL, "alvq_adam_advance_f32: null pointer");
-  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scalars, lr, beta1, beta2, grad_scale);
+  int* flag = prev_skip ? fx_range_flag_ptr() : nullptr;
+  int* sticky = prev_skip ? fx_range_sticky_ptr() : nullptr;
+  ALVQ_REQUIRE(!prev_skip || (flag && sticky), ALVQ_EINVAL, "alvq_adam_advance_f32: the range flag's device address is unavailable");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scalars, lr, beta1, beta2, grad_scale,
+                     prev_skip, flag, sticky);
   return check_launch("alvq_adam_advance_f32");
+}
+
+extern "C" int alvq_range_flag_to_slot(float* slot, void* stream) {
+  ALVQ_REQUIRE(slot, ALVQ_EINVAL, "alvq_range_flag_to_slot: null pointer");
+  int* flag = fx_range_flag_ptr();
+  ALVQ_REQUIRE(flag, ALVQ_EINVAL, "alvq_range_flag_to_slot: the range flag's device address is unavailable");
+  hipLaunchKernelGGL(range_flag_to_slot_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot, (const int*)flag);
+  return check_launch("alvq_range_flag_to_slot");
 }

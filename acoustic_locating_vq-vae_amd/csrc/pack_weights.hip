@@ -107,12 +107,14 @@ struct AdamPackBatch {
   AdamPackDesc d[AP_MAX];
   int n;
   const float* sc;                  // {lr / bias_correction1, sqrt(bias_correction2), grad_scale} (alvq_adam_advance_f32)
+  const float* skip;                // nullable; non-zero: the step saturated an fp16-range format -- nothing is updated
   float beta1, beta2, eps;
 };
 
 template <int PLANES>
 __global__ __launch_bounds__(256) void adam_pack_batch_kernel(AdamPackBatch b) {
   __shared__ float tile[3][32][65];
+  if (b.skip && *b.skip != 0.f) return;      // skipped step: weights, moments and packed images stay as they are
   if (PLANES == 3) fx_saturating_conversions();
   int di = 0;
   for (int i = 1; i < b.n; ++i)
@@ -174,7 +176,8 @@ struct AdamSegs {
   int n;
 };
 __global__ __launch_bounds__(256) void adam_segments_kernel(float* p, const float* g, float* m, float* v, AdamSegs s, const float* sc,
-                                                            float beta1, float beta2, float eps) {
+                                                            float beta1, float beta2, float eps, const float* skip) {
+  if (skip && *skip != 0.f) return;
   int si = 0;
   for (int i = 1; i < s.n; ++i)
     if ((int)blockIdx.x >= s.blk0[i]) si = i;
@@ -232,7 +235,7 @@ extern "C" int alvq_pack_weights_bf16_batch(const alvq_pack_desc* descs, int n, 
 }
 
 extern "C" int alvq_adam_pack_batch(const alvq_adam_pack_desc* descs, int n, int planes, const float* scalars, float beta1,
-                                    float beta2, float eps, void* stream) {
+                                    float beta2, float eps, const float* skip, void* stream) {
   ALVQ_REQUIRE(descs && n > 0 && scalars, ALVQ_EINVAL, "alvq_adam_pack_batch: no descriptors / scalars");
   ALVQ_REQUIRE(planes >= 1 && planes <= 3, ALVQ_EINVAL, "alvq_adam_pack_batch: planes=%d (1, 2 or 3)", planes);
   for (int i = 0; i < n; ++i) {
@@ -243,7 +246,7 @@ extern "C" int alvq_adam_pack_batch(const alvq_adam_pack_desc* descs, int n, int
   for (int i0 = 0; i0 < n; i0 += AP_MAX) {
     AdamPackBatch b{};
     b.n = n - i0 < AP_MAX ? n - i0 : AP_MAX;
-    b.sc = scalars; b.beta1 = beta1; b.beta2 = beta2; b.eps = eps;
+    b.sc = scalars; b.skip = skip; b.beta1 = beta1; b.beta2 = beta2; b.eps = eps;
     int blocks = 0;
     for (int i = 0; i < b.n; ++i) {
       const alvq_adam_pack_desc& s = descs[i0 + i];
@@ -266,7 +269,7 @@ extern "C" int alvq_adam_pack_batch(const alvq_adam_pack_desc* descs, int n, int
 
 extern "C" int alvq_adam_segments_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* lo,
                                       const int64_t* hi, int nseg, const float* scalars, float beta1, float beta2, float eps,
-                                      void* stream) {
+                                      const float* skip, void* stream) {
   ALVQ_REQUIRE(param && grad && exp_avg && exp_avg_sq && scalars && lo && hi, ALVQ_EINVAL, "alvq_adam_segments_f32: null pointer");
   ALVQ_REQUIRE(nseg > 0, ALVQ_EINVAL, "alvq_adam_segments_f32: no segments");
   for (int i0 = 0; i0 < nseg; i0 += AS_MAX) {
@@ -280,7 +283,7 @@ extern "C" int alvq_adam_segments_f32(float* param, const float* grad, float* ex
       blocks += (int)((hi[i0 + i] - lo[i0 + i] + 1023) / 1024);
     }
     hipLaunchKernelGGL(adam_segments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, s, scalars,
-                       beta1, beta2, eps);
+                       beta1, beta2, eps, skip);
     int rc = check_launch("alvq_adam_segments_f32");
     if (rc) return rc;
   }

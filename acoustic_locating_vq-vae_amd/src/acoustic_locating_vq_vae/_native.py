@@ -52,8 +52,9 @@ _SIGNATURES = {
     "alvq_row_mean_backward_f32": (_i32, [_c_void_p] * 2 + [_i64, _i32, _c_void_p]),
     "alvq_transpose_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_adam_f32": (_i32, [_c_void_p] * 4 + [_i64, _i32, _f32, _f32, _f32, _f32, _f32, _c_void_p]),
-    "alvq_adam_dev_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p, _f32, _f32, _f32, _c_void_p]),
-    "alvq_adam_advance_f32": (_i32, [_c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_void_p]),
+    "alvq_adam_dev_f32": (_i32, [_c_void_p] * 4 + [_i64, _c_void_p, _f32, _f32, _f32, _c_void_p, _c_void_p]),
+    "alvq_adam_advance_f32": (_i32, [_c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_void_p, _c_void_p]),
+    "alvq_range_flag_to_slot": (_i32, [_c_void_p, _c_void_p]),
     "alvq_stft_power_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_stft_power_f64": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_stft_complex_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
@@ -66,8 +67,8 @@ _SIGNATURES = {
     "alvq_packed_weight_elems": (_i64, [_i32, _i32, _i32]),
     "alvq_pack_weight_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_pack_weights_bf16_batch": (_i32, [_c_void_p, _i32, _i32, _c_void_p]),
-    "alvq_adam_pack_batch": (_i32, [_c_void_p, _i32, _i32, _c_void_p, _f32, _f32, _f32, _c_void_p]),
-    "alvq_adam_segments_f32": (_i32, [_c_void_p] * 4 + [_c_void_p, _c_void_p, _i32, _c_void_p, _f32, _f32, _f32, _c_void_p]),
+    "alvq_adam_pack_batch": (_i32, [_c_void_p, _i32, _i32, _c_void_p, _f32, _f32, _f32, _c_void_p, _c_void_p]),
+    "alvq_adam_segments_f32": (_i32, [_c_void_p] * 4 + [_c_void_p, _c_void_p, _i32, _c_void_p, _f32, _f32, _f32, _c_void_p, _c_void_p]),
     "alvq_ncl_to_nlc_bf16": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_nlc_to_ncl_f32": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p]),
     "alvq_relu_mask_bf16": (_i32, [_c_void_p] * 3 + [_i64, _c_void_p]),
@@ -333,6 +334,14 @@ def _defer_descs(defer, ws_ptr, dw, dbias, scale, nseg, B, C, M, L, KW, w_layout
     """``scale``: the 4-float loss-scale state of the gradient chain (its 1/S is read by the reduction), or None."""
     L_ = lib()
     scale_ptr = _sptr(scale, 1)
+    # the batch launch sums its descriptors in concurrent workgroups: two descriptors accumulating into ONE destination
+    # (a shared residual weight used by more than four layers, i.e. outside the fused multi-segment launch) would race on
+    # ``dst += sum``.  Sum what is pending first -- stream order then serialises the two accumulations, as the
+    # per-launch reductions did (round-3 advisor finding).
+    dsts = {dw.data_ptr()} | ({dbias.data_ptr()} if dbias is not None else set())
+    if any(d.dst in dsts for d in defer):
+        wgrad_reduce_batch(defer)
+        del defer[:]
     if scale is not None and hasattr(defer, "keep"):
         defer.keep.append(scale)
     splits = L_.alvq_conv1d_wgrad_bf16_splits(B, C, M, L, KW, nseg, int(dbias is not None))
@@ -575,20 +584,30 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, beta1=0.9, beta2=
                                float(beta2), float(eps), float(grad_scale), _stream()), "alvq_adam_f32")
 
 
-def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, scalars, beta1=0.9, beta2=0.999, eps=1e-8, skip=None):
     """Adam with {lr/bc1, sqrt(bc2), grad_scale} read from the first 3 floats of the device tensor ``scalars``
-    (graph-replayable; ``adam_advance`` maintains them)."""
+    (graph-replayable; ``adam_advance`` maintains them).  ``skip``: the skip slot (a device float tensor; non-zero = leave
+    everything untouched), or None."""
     _check(lib().alvq_adam_dev_f32(_ptr(param, name="param"), _ptr(grad, name="grad"), _ptr(exp_avg, name="exp_avg"),
                                    _ptr(exp_avg_sq, name="exp_avg_sq"), param.numel(), _ptr(scalars, name="scalars"),
-                                   float(beta1), float(beta2), float(eps), _stream()), "alvq_adam_dev_f32")
+                                   float(beta1), float(beta2), float(eps), _ptr(skip, name="skip"), _stream()), "alvq_adam_dev_f32")
 
 
-def adam_advance(scalars, lr, beta1=0.9, beta2=0.999, grad_scale=1.0):
-    """Device-side ``step += 1`` on the 4-float tensor ``scalars`` = {lr/bc1, sqrt(bc2), grad_scale, step}."""
-    if scalars.numel() != 4:
-        raise RuntimeError("adam_advance: scalars must hold 4 floats")
+ADAM_SCALARS = 8     # floats of the device state: {lr/bc1, sqrt(bc2), grad_scale, step, skipped steps, -, -, -}
+
+
+def adam_advance(scalars, lr, beta1=0.9, beta2=0.999, grad_scale=1.0, prev_skip=None):
+    """Device-side ``step += 1`` on the 8-float tensor ``scalars`` = {lr/bc1, sqrt(bc2), grad_scale, step, skipped, ...}.
+    ``prev_skip``: the skip slot still holding the previous step's verdict -- a skipped step does not count."""
+    if scalars.numel() != ADAM_SCALARS:
+        raise RuntimeError("adam_advance: scalars must hold %d floats" % ADAM_SCALARS)
     _check(lib().alvq_adam_advance_f32(_ptr(scalars, name="scalars"), float(lr), float(beta1), float(beta2),
-                                       float(grad_scale), _stream()), "alvq_adam_advance_f32")
+                                       float(grad_scale), _ptr(prev_skip, name="prev_skip"), _stream()), "alvq_adam_advance_f32")
+
+
+def range_flag_to_slot(slot):
+    """slot[0] = 1.0 if the fp16-range flag holds a bit raised since the step's guarded ``adam_advance``, else 0.0."""
+    _check(lib().alvq_range_flag_to_slot(_ptr(slot, name="slot"), _stream()), "alvq_range_flag_to_slot")
 
 
 def stft_power(wave, n_fft=400, hop=160):
@@ -844,7 +863,7 @@ class AdamPackDesc(ctypes.Structure):
                 ("KW", ctypes.c_int32)]
 
 
-def adam_pack_batch(entries, planes, scalars, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_pack_batch(entries, planes, scalars, beta1=0.9, beta2=0.999, eps=1e-8, skip=None):
     """entries: [(w, g, m, v fp32 views of one conv weight and its Adam state, packed OIK image or None, packed IOK image or
     None)] -- Adam's update and the re-pack of every image in one launch."""
     if not entries:
@@ -856,10 +875,10 @@ def adam_pack_batch(entries, planes, scalars, beta1=0.9, beta2=0.999, eps=1e-8):
         d.wp_iok = iok.data_ptr() if iok is not None else None
         d.dim0, d.dim1, d.KW = w.shape
     _check(lib().alvq_adam_pack_batch(ctypes.addressof(arr), len(entries), planes, _ptr(scalars, name="scalars"), float(beta1),
-                                      float(beta2), float(eps), _stream()), "alvq_adam_pack_batch")
+                                      float(beta2), float(eps), _ptr(skip, name="skip"), _stream()), "alvq_adam_pack_batch")
 
 
-def adam_segments(param, grad, exp_avg, exp_avg_sq, segments, scalars, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_segments(param, grad, exp_avg, exp_avg_sq, segments, scalars, beta1=0.9, beta2=0.999, eps=1e-8, skip=None):
     """Adam over the element ranges [(lo, hi), ...] of the flat buffers, one launch."""
     segments = [(int(a), int(b)) for a, b in segments if b > a]
     if not segments:
@@ -868,7 +887,8 @@ def adam_segments(param, grad, exp_avg, exp_avg_sq, segments, scalars, beta1=0.9
     hi = (ctypes.c_int64 * len(segments))(*[b for _, b in segments])
     _check(lib().alvq_adam_segments_f32(_ptr(param, name="param"), _ptr(grad, name="grad"), _ptr(exp_avg, name="exp_avg"),
                                         _ptr(exp_avg_sq, name="exp_avg_sq"), lo, hi, len(segments), _ptr(scalars, name="scalars"),
-                                        float(beta1), float(beta2), float(eps), _stream()), "alvq_adam_segments_f32")
+                                        float(beta1), float(beta2), float(eps), _ptr(skip, name="skip"), _stream()),
+           "alvq_adam_segments_f32")
 
 
 def relu_mask_bf16(dy, t):

@@ -39,12 +39,18 @@ Two precisions share these chains through a small "engine" object:
   5e-4 ... 7e-4 of the fp32 result at the default configs, 1.3e-3 measured on a 48-channel model -- at the north star's 1e-3,
   not safely inside it -- and the decoder-side gradients see ~30x the ReLU gate flips.  0.87x the f16mx_hb step time.
 
-Select with ``set_compute_dtype(...)`` or the environment variable ``ALVQ_DTYPE``.
-DEFAULT (round 3): ``f16mx_hb`` -- the fastest mode that holds the reference's forward results (codebook indices
-bit-exact, outputs within 2e-5 on the default-config goldens), so that ``scripts/train_speech.py`` unchanged runs at ~7x
-the ``f32`` mode's rate.  ``ALVQ_DTYPE=f16mx`` keeps the cross terms in the backward pass too; ``ALVQ_DTYPE=f32`` selects
-the exact-fp32 MFMA mode (strict gradient parity, 1e-6).  The f16mx modes carry fp16's range: activations must stay below
-65504 (``_native.f16mx_range_flag()`` reports inputs that do not).
+* ``x3mx_hb`` -- (round 4; the DEFAULT) per-role arithmetic: everything the codebook indices depend on -- the encoder
+  and the pre-VQ convolution -- runs the bf16x3 forward (6.6e-6: every index of every reference golden, the 1.8e-6 RIR
+  near-tie included), the decoder's forward runs f16mx (2e-5 on the reconstruction), and every backward product is ONE 16-bit
+  MFMA: bf16 on the hi planes of the encoder's saved activations, fp16 under the loss scale on the H planes of the decoder's.
+
+Select with ``set_compute_dtype(...)`` or the environment variable ``ALVQ_DTYPE``.  User-selectable modes (``MODES``):
+``x3mx_hb`` (default), ``f16mx_hb`` (2-3 % faster; resolves reference near-ties down to ~4e-6 relative), ``bf16x3_hb``,
+``f32`` (exact-fp32 MFMA: strict gradient parity, 1e-6), ``bf16`` (throughput; ~1 % of the indices differ).  ``f16mx``,
+``bf16x3`` and ``f16mx_hd`` are INTERNAL engines since round 4 (their forwards live on inside the ``_hb`` modes; the
+kernel-level tests reach them with ``set_compute_dtype(name, internal=True)``).  The f16mx-range modes carry fp16's range:
+activations must stay below 65504; a step whose values saturate is SKIPPED by the Trainer's optimiser launch (csrc/
+pack_weights.hip) and counted (``_native.f16mx_range_state()``).
 """
 from __future__ import annotations
 
@@ -57,17 +63,25 @@ from . import _native as N
 
 OIK, IOK = N.W_OIK, N.W_IOK
 
-DEFAULT_DTYPE = "f16mx_hb"
+DEFAULT_DTYPE = "x3mx_hb"
+MODES = ("x3mx_hb", "f16mx_hb", "bf16x3_hb", "f32", "bf16")      # user-selectable (ALVQ_DTYPE / set_compute_dtype)
+INTERNAL_MODES = ("f16mx", "bf16x3", "f16mx_hd")                 # engines kept for the kernel-level tests only
 _DTYPE = os.environ.get("ALVQ_DTYPE", DEFAULT_DTYPE)
-if _DTYPE not in ("f32", "bf16", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd", "bf16x3_hb"):
-    raise ValueError("ALVQ_DTYPE must be 'f32', 'bf16', 'bf16x3', 'bf16x3_hb', 'f16mx', 'f16mx_hb' or 'f16mx_hd', got %r" % (_DTYPE,))
+if _DTYPE not in MODES:
+    raise ValueError("ALVQ_DTYPE must be one of %s, got %r" % (", ".join(repr(m) for m in MODES), _DTYPE))
 
 
-def set_compute_dtype(name):
+def set_compute_dtype(name, internal=False):
+    """Select the arithmetic of every later forward.  ``internal=True`` also admits the retired engines (tests)."""
     global _DTYPE
-    if name not in MODES:
+    if name not in MODES and not (internal and name in INTERNAL_MODES):
         raise ValueError("compute dtype must be one of %s, got %r" % (", ".join(repr(m) for m in MODES), name))
     _DTYPE = name
+
+
+def has_fp16_range(mode=None):
+    """Does the mode keep any tensor in an fp16-range format (f16mx planes, fp16 gradients)?"""
+    return (mode or _DTYPE) in ("x3mx_hb", "f16mx_hb", "f16mx", "f16mx_hd")
 
 
 def get_compute_dtype():
@@ -123,6 +137,31 @@ class deferred_reduce:
     def __exit__(self, *exc):
         global _DEFERRED
         _DEFERRED = self.prev
+
+
+# The module API without a Trainer (scripts/train_speech.py's own loop: model(x); loss.backward(); torch.optim.Adam.step()) has
+# nobody watching the fp16 range flag: poll it every ALVQ_RANGE_CHECK_EVERY (200) training-mode forwards -- one host read,
+# next to the script's own two .item() syncs per step (train_speech.py:93-94) -- and warn.  Nothing can be skipped here: the
+# optimiser is torch's.
+_API_FORWARDS = 0
+
+
+def note_training_forward(device):
+    global _API_FORWARDS
+    if device.type != "cuda" or _SINKS_ACTIVE or not has_fp16_range() or torch.cuda.is_current_stream_capturing():
+        return
+    every = int(os.environ.get("ALVQ_RANGE_CHECK_EVERY", "200"))
+    _API_FORWARDS += 1
+    if every <= 0 or _API_FORWARDS < every:
+        return
+    _API_FORWARDS = 0
+    flag = N.f16mx_range_flag(reset=True, device=device)
+    if flag:
+        import warnings
+        warnings.warn("acoustic_locating_vq_vae: fp16 range flag %d in mode %s -- a value entering or produced inside the "
+                      "fp16-range formats reached 65504 (or was NaN) during the last %d forward / backward passes; those steps "
+                      "are saturated.  ALVQ_DTYPE=bf16x3_hb or f32 have fp32 range; train_step.Trainer skips such steps."
+                      % (flag, _DTYPE, every), RuntimeWarning)
 
 
 def _sink(t):
@@ -203,18 +242,22 @@ class PackPool:
         return [k for k, v in self._adam_version.items() if self._eligible[k[0]]._version != v]
 
     def adam_groups(self):
-        """({data_ptr: {layout: image}}, planes) over the dynamic entries, or (None, None) when they do not share one
-        format (then the optimiser and the re-pack stay separate launches)."""
-        groups, planes = {}, None
+        """{data_ptr: (planes, {layout: image})} over the dynamic entries, or None when some parameter has images in two
+        formats (a mode switch on a live Trainer: then the optimiser and the re-pack stay separate launches).  In the
+        per-role modes the encoder's and the decoder's weights carry different formats -- one fused launch per format."""
+        groups = {}
         for (ptr, layout, pl), (img, _) in self._entries.items():
             if self._is_static(ptr):
                 continue
-            if planes is None:
-                planes = pl
-            elif pl != planes:
-                return None, None
-            groups.setdefault(ptr, {})[layout] = img
-        return (groups, planes) if groups else (None, None)
+            hit = groups.setdefault(ptr, (pl, {}))
+            if hit[0] != pl:
+                return None
+            hit[1][layout] = img
+        return groups or None
+
+    def forget_adam_marks(self):
+        """The optimiser ran WITHOUT writing the images (unfused path): every image is stale until the next refresh."""
+        self._adam_version.clear()
 
     def mark_adam_packed(self, ptrs):
         for key in self._entries:
@@ -500,11 +543,13 @@ class _F16DecoderEngine(_F16MXHBEngine):
         return N.ncl_to_nlc(x, 1, "f16", N.grad_scale(x) if grad else None)
 
 
+# x3mx_hb has no engine of its own: its parts run bf16x3_hb's (encoder side, and any module used on its own) and f16mx_hb's
+# (decoder) engines, so a saved node re-wraps its activations by the name of the engine that made them
 _ENGINES = {"f32": _F32Engine, "bf16": _BF16Engine, "bf16x3": _BF16x3Engine, "f16mx": _F16MXEngine, "f16mx_hb": _F16MXHBEngine,
-            "f16mx_hd": _F16MXHDEngine, "bf16x3_hb": _BF16x3HBEngine}
-MODES = tuple(_ENGINES)
-_ROLE_ENGINES = {("f16mx_hd", "decoder"): _F16DecoderEngine}
+            "f16mx_hd": _F16MXHDEngine, "bf16x3_hb": _BF16x3HBEngine, "x3mx_hb": _BF16x3HBEngine}
+_ROLE_ENGINES = {("f16mx_hd", "decoder"): _F16DecoderEngine, ("x3mx_hb", "decoder"): _F16MXHBEngine}
 _ENGINES_BY_NAME = dict(_ENGINES, f16dec=_F16DecoderEngine)
+assert set(MODES) | set(INTERNAL_MODES) == set(_ENGINES)
 
 
 def _engine(name=None, role=None):

@@ -41,14 +41,19 @@ def unique_trainable(params):
 
 
 class FlatBuffers:
-    """Re-point ``params`` (and their grads) at slices of two flat buffers.  Device agnostic."""
+    """Re-point ``params`` (and their grads) at slices of two flat buffers.  Device agnostic.
+
+    Both buffers start with a header of ``_ALIGN`` floats.  Element 0 of the GRADIENT buffer is the step's SKIP SLOT: the
+    last launch of a backward writes 1.0 there if the step saturated an fp16-range format (``N.range_flag_to_slot``), the
+    step's all-reduce sums it over the ranks with the gradients -- so every rank reaches the same verdict -- and the
+    optimiser launches leave everything untouched when it is non-zero (``FlatAdam``)."""
 
     def __init__(self, params):
         self.params = unique_trainable(params)
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        self.offsets, total = [], 0
+        self.offsets, total = [], _ALIGN
         for p in self.params:
             if p.device != dev or p.dtype != torch.float32:
                 raise ValueError("all parameters must be fp32 on one device")
@@ -62,6 +67,7 @@ class FlatBuffers:
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+        self.skip_slot = self.grad[0:1]
 
     def zero_grad(self):
         """Keeps the views alive (optimizer.zero_grad(set_to_none=True) would drop them)."""
@@ -93,7 +99,7 @@ class FlatBuffers:
             raise ValueError("bucket parameters are not a contiguous run of the flat buffer")
         last = idx[-1]
         hi = self.offsets[last + 1] if last + 1 < len(self.offsets) else self.grad.numel()
-        return self.offsets[idx[0]], hi
+        return (0 if idx[0] == 0 else self.offsets[idx[0]]), hi      # a prefix span takes the header (the skip slot) along
 
     def sync_span(self, lo, hi, group=None, force=False):
         """Asynchronous all-reduce(sum) of grad[lo:hi); returns the work handle (None without a process group).  The
@@ -115,13 +121,16 @@ class FlatAdam:
     staged through host memory, so a host that queues many steps ahead of the device (graph replay does) cannot
     overwrite a step's scalars before that step's Adam launch has read them."""
 
-    def __init__(self, buffers: FlatBuffers, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, buffers: FlatBuffers, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, guard=False):
+        """``guard``: honour the buffers' skip slot -- a step whose slot is non-zero is not applied (parameters, moments,
+        packed images untouched), does not advance the step count and is counted in ``scalars[4]``."""
         self.b = buffers
         self.lr, self.betas, self.eps = lr, betas, eps
+        self.guard = bool(guard) and buffers.flat.is_cuda
         self.exp_avg = torch.zeros_like(buffers.flat)
         self.exp_avg_sq = torch.zeros_like(buffers.flat)
-        self.step_count = 0                                   # host mirror of scalars[3]
-        self.scalars = torch.zeros(4, device=buffers.flat.device, dtype=torch.float32)
+        self.step_count = 0                                   # steps ATTEMPTED on the host; scalars[3] = steps applied
+        self.scalars = torch.zeros(N.ADAM_SCALARS, device=buffers.flat.device, dtype=torch.float32)
 
     def set_step(self, step):
         """Resume from a checkpointed step count."""
@@ -130,7 +139,16 @@ class FlatAdam:
 
     def prepare(self, grad_scale=1.0):
         self.step_count += 1
-        N.adam_advance(self.scalars, self.lr, self.betas[0], self.betas[1], grad_scale)
+        N.adam_advance(self.scalars, self.lr, self.betas[0], self.betas[1], grad_scale,
+                       prev_skip=self.b.skip_slot if self.guard else None)
+
+    def skipped_steps(self, reset=True):
+        """Steps the guard skipped since the counter was last reset (one host sync).  The step in flight is counted by the
+        NEXT ``prepare``."""
+        n = int(self.scalars[4].item())
+        if reset and n:
+            self.scalars[4] = 0.0
+        return n
 
     def apply(self, skip=(), pack_pool=None):
         """One Adam launch over the flat buffer; ``skip`` = [lo, hi) element ranges that received no gradient this
@@ -141,25 +159,28 @@ class FlatAdam:
         ONE fused launch that also writes those images while the new weights are in registers (``alvq_adam_pack_batch``;
         round 2 re-read every weight in a separate packing launch at the start of the next step), everything else --
         biases, the codebook -- by one segmented launch.  Same arithmetic, bit for bit."""
-        groups, planes = pack_pool.adam_groups() if (pack_pool is not None and os.environ.get("ALVQ_ADAM_PACK", "1") != "0") \
-            else (None, None)
+        groups = pack_pool.adam_groups() if (pack_pool is not None and os.environ.get("ALVQ_ADAM_PACK", "1") != "0") else None
+        skip_ptr = self.b.skip_slot if self.guard else None
         if groups:
             skipped = [(int(a), int(b)) for a, b in skip]
-            entries, segments, fused = [], [], set()
+            by_planes, segments, fused = {}, [], set()
             for p, off in zip(self.b.params, self.b.offsets):
                 n = p.numel()
                 if any(a <= off and off + n <= b for a, b in skipped):
                     continue
-                imgs = groups.get(p.data_ptr()) if p.dim() == 3 else None
-                if imgs:
-                    entries.append((p.data, p.grad, self.exp_avg[off:off + n].view(p.shape), self.exp_avg_sq[off:off + n].view(p.shape),
-                                    imgs.get(N.W_OIK), imgs.get(N.W_IOK)))
+                hit = groups.get(p.data_ptr()) if p.dim() == 3 else None
+                if hit:
+                    planes, imgs = hit
+                    by_planes.setdefault(planes, []).append(
+                        (p.data, p.grad, self.exp_avg[off:off + n].view(p.shape), self.exp_avg_sq[off:off + n].view(p.shape),
+                         imgs.get(N.W_OIK), imgs.get(N.W_IOK)))
                     fused.add(p.data_ptr())
                 else:
                     segments.append((off, off + n))
-            N.adam_pack_batch(entries, planes, self.scalars, self.betas[0], self.betas[1], self.eps)
+            for planes, entries in by_planes.items():       # one launch per weight format (per-role modes: two)
+                N.adam_pack_batch(entries, planes, self.scalars, self.betas[0], self.betas[1], self.eps, skip=skip_ptr)
             N.adam_segments(self.b.flat, self.b.grad, self.exp_avg, self.exp_avg_sq, segments, self.scalars, self.betas[0],
-                            self.betas[1], self.eps)
+                            self.betas[1], self.eps, skip=skip_ptr)
             pack_pool.mark_adam_packed(fused)
             _ops.bump_weight_epoch()
             return
@@ -167,8 +188,10 @@ class FlatAdam:
         for s_lo, s_hi in sorted(skip) + [(self.b.flat.numel(), self.b.flat.numel())]:
             if s_lo > lo:
                 N.adam_step_dev(self.b.flat[lo:s_lo], self.b.grad[lo:s_lo], self.exp_avg[lo:s_lo],
-                                self.exp_avg_sq[lo:s_lo], self.scalars, self.betas[0], self.betas[1], self.eps)
+                                self.exp_avg_sq[lo:s_lo], self.scalars, self.betas[0], self.betas[1], self.eps, skip=skip_ptr)
             lo = max(lo, s_hi)
+        if pack_pool is not None:
+            pack_pool.forget_adam_marks()   # the images were NOT written by this update: every one is stale (round-3 advisor)
         _ops.bump_weight_epoch()        # parameter memory changed behind torch's version counters: packed images are stale
 
     def step(self, grad_scale=1.0):
@@ -228,15 +251,22 @@ class Trainer:
     """
 
     def __init__(self, model, kind="speech", lr=1e-3, group=None, grad_buckets=None, force_collective=None,
-                 range_check_every=None):
+                 range_check_every=None, strict_range=None):
         """``force_collective`` (or ALVQ_FORCE_COLLECTIVE=1): issue the step's all-reduce even in a one-rank process
         group, where it is the identity -- so that the RCCL call between the backward and the Adam launch can be
-        executed (and is tested, tests/test_rccl_gpu.py) on a single-GPU box."""
+        executed (and is tested, tests/test_rccl_gpu.py) on a single-GPU box.
+
+        fp16-range modes (x3mx_hb, f16mx_hb): a step in which any value saturated at 65504 (or was NaN) -- on ANY rank -- is
+        SKIPPED on the device: the optimiser launches leave parameters, moments and packed weights untouched and the step
+        does not count (no host sync; ALVQ_SKIP_SATURATED=0 restores apply-and-warn).  Every ``range_check_every`` steps
+        (ALVQ_RANGE_CHECK_EVERY; default 200, 0 = never) the skipped-step counter and the sticky range flag are read back
+        -- ONE host sync -- and reported: a RuntimeWarning, or with ``strict_range`` (ALVQ_RANGE_STRICT=1) a
+        FloatingPointError when steps were skipped."""
         self.model, self.kind, self.group = model, kind, group
-        # fp16-range formats (f16mx, f16mx_hb): every `range_check_every` steps (ALVQ_RANGE_CHECK_EVERY; default 200, 0 = never)
-        # the sticky range flag is read back -- ONE host sync -- and a set flag is reported: some value saturated at 65504
         self.range_check_every = int(os.environ.get("ALVQ_RANGE_CHECK_EVERY", "200")) if range_check_every is None \
             else int(range_check_every)
+        self.strict_range = (os.environ.get("ALVQ_RANGE_STRICT", "0") != "0") if strict_range is None else bool(strict_range)
+        self.skipped_steps = 0                # total reported by check_range so far
         self._steps_since_check = 0
         self.force_collective = (os.environ.get("ALVQ_FORCE_COLLECTIVE", "0") != "0") if force_collective is None \
             else bool(force_collective)
@@ -255,7 +285,7 @@ class Trainer:
         use_pool = self.buffers.flat.is_cuda and os.environ.get("ALVQ_PACK_POOL", "1") != "0"
         self.pack_pool = _ops.PackPool(list(model.parameters()), dynamic=self.buffers.params) if use_pool else None
         self.buffers.broadcast_params(group=group)
-        self.opt = FlatAdam(self.buffers, lr=lr)
+        self.opt = FlatAdam(self.buffers, lr=lr, guard=os.environ.get("ALVQ_SKIP_SATURATED", "1") != "0")
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.grad_scale = 1.0 / world
         self._graph = None
@@ -338,7 +368,15 @@ class Trainer:
                 self._cut = tap[0] if tap else None
             if reductions:
                 N.wgrad_reduce_batch(reductions)
+            if self._cut is None:
+                self._post_verdict()
         return loss.detach(), recon_error.detach(), perplexity.detach()
+
+    def _post_verdict(self):
+        """Last launch of the step's backward: did this step saturate an fp16-range format?  -> the skip slot, which the
+        step's all-reduce then sums over the ranks (it is element 0 of the flat gradient buffer)."""
+        if getattr(self.opt, "guard", False) and _ops.has_fp16_range():
+            N.range_flag_to_slot(self.buffers.skip_slot)
 
     def _body_late(self):
         """Second part of the backward: the encoder and the pre-VQ conv, from the latent's gradient."""
@@ -350,6 +388,7 @@ class Trainer:
             z.backward(leaf.grad)
             if reductions:
                 N.wgrad_reduce_batch(reductions)
+            self._post_verdict()
 
     def _sync_early(self):
         return self.buffers.sync_span(*self._buckets[0], group=self.group, force=self.force_collective) if self._buckets else None
@@ -373,7 +412,8 @@ class Trainer:
         and the step count.  The reference only ever saves the model (``torch.save(model, ...)``), so its resumed
         runs restart Adam from zero; with this a resumed step is bitwise the step that would have come next."""
         return {"model": self.model.state_dict(), "exp_avg": self.opt.exp_avg.clone(), "exp_avg_sq": self.opt.exp_avg_sq.clone(),
-                "step": self.opt.step_count, "numel": self.buffers.flat.numel(), "kind": self.kind}
+                "step": int(self.opt.scalars[3].item()),          # steps APPLIED (a skipped step does not count)
+                "numel": self.buffers.flat.numel(), "kind": self.kind}
 
     def load_state_dict(self, state):
         if state["numel"] != self.buffers.flat.numel() or state["kind"] != self.kind:
@@ -390,17 +430,24 @@ class Trainer:
         return [m for m in self.model.modules() if isinstance(m, Jitter)]
 
     def check_range(self):
-        """Read (and clear) the fp16 range flag of the device: 0, or bits {1: an input reached 65504, 2: an input was NaN,
-        4: a convolution produced such a value}.  One host sync; ``step`` calls it every ``range_check_every`` steps in the
-        f16mx modes and warns."""
-        if not (self.buffers.flat.is_cuda and _ops.get_compute_dtype().startswith("f16mx")):
+        """Read (and clear) the device's fp16 range state: the sticky flag -- 0, or bits {1: an input reached 65504, 2: an
+        input was NaN, 4: a convolution produced such a value} -- and the number of steps the optimiser skipped because of
+        it.  One host sync; ``step`` calls it every ``range_check_every`` steps in the fp16-range modes.  Returns the flag."""
+        if not (self.buffers.flat.is_cuda and _ops.has_fp16_range()):
             return 0
         flag = N.f16mx_range_flag(reset=True, device=self.buffers.flat.device)
-        if flag:
+        skipped = self.opt.skipped_steps(reset=True) if self.opt.guard else 0
+        self.skipped_steps += skipped
+        if flag or skipped:
+            msg = ("acoustic_locating_vq_vae: fp16 range flag %d in mode %s -- a value entering or produced inside the fp16-range "
+                   "formats reached 65504 (or was NaN) since the last check; %s.  ALVQ_DTYPE=bf16x3_hb or f32 have fp32 range."
+                   % (flag, _ops.get_compute_dtype(),
+                      ("%d optimiser step(s) were SKIPPED (parameters untouched)" % skipped) if self.opt.guard
+                      else "the results of those steps are saturated"))
+            if self.strict_range and skipped:
+                raise FloatingPointError(msg)
             import warnings
-            warnings.warn("acoustic_locating_vq_vae: fp16 range flag %d in mode %s -- a value entering or produced inside the "
-                          "fp16-range formats reached 65504 (or was NaN) since the last check; results of those steps are "
-                          "saturated.  ALVQ_DTYPE=bf16x3 or f32 have fp32 range." % (flag, _ops.get_compute_dtype()), RuntimeWarning)
+            warnings.warn(msg, RuntimeWarning)
         return flag
 
     def step(self, raw, wiener=None):
@@ -425,6 +472,12 @@ class Trainer:
         replay = self._graph is not None and tuple(raw.shape) == tuple(self._static_raw.shape) and \
             (wiener is None or tuple(wiener.shape) == tuple(self._static_wiener.shape))
         if not replay:
+            if self._graph is not None:
+                # the ragged batch of a captured trainer: the jitters are pinned to their static buffers (same L), which
+                # only refresh() redraws -- without it the step would reuse the previous step's columns and leave the
+                # np.random stream one draw behind the reference's from here on (round-3 advisor finding)
+                for j in self._graph_jitters:
+                    j.refresh()
             self.opt.prepare(self.grad_scale)
             out = self._body(raw, wiener)
             early = self._sync_early()

@@ -46,6 +46,8 @@ class ConvolutionalVQVAE(nn.Module):
                                    enc._residual_stack._num_residual_layers)
 
     def forward(self, x):
+        if self.training:
+            _ops.note_training_forward(x.device)
         z = self._latent(x)
         if _ops._LATENT_TAP is not None and z.requires_grad:
             # train_step.Trainer runs the backward in two parts (decoder + quantiser, then encoder) so that the

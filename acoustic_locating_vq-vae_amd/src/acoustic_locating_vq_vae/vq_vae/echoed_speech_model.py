@@ -7,7 +7,7 @@ from torch import nn
 
 from acoustic_locating_vq_vae.vq_vae.deconvolutional_decoder import DeconvolutionalDecoder
 
-from .. import _native
+from .. import _ops
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
@@ -29,6 +29,8 @@ class EchoedSpeechReconModel(nn.Module):
         self.flag_train_encoder = flag
 
     def forward(self, spec_in, spec_in_rir):
+        if self.training:
+            _ops.note_training_forward(spec_in.device)
         grad = self.flag_train_encoder
         with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
             # frozen encoders build no graph and keep no activations (the reference detaches afterwards, :53-54)

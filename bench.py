@@ -7,28 +7,28 @@
 
 A "step" = standardise -> encoder -> pre-VQ conv -> VQ -> decoder -> MSE -> backward -> [one RCCL all-reduce of
 the flat gradient buffer] -> Adam, on a synthetic (B,201,500) batch already resident in HBM (speech ctor of
-scripts/train_speech.py:152-153, B=64 per GPU, weak scaling).  Prints ONE JSON line on rank 0.
+scripts/train_speech.py:152-153, B=64 per GPU, weak scaling).
 
-What the line holds (N=1):
-  value / roofline ........ the headline mode (--dtype, default f16mx_hb = the fastest mode that HOLDS the north star's parity:
-                            codebook indices bit-exact, outputs within 1e-3 of the fp32 reference; its forward is f16mx's
-                            bit for bit, its gradients agree with fp32 as closely as f16mx's do), hipGraph replay;
-                            `roofline` is KERNEL-ONLY (the dominant conv kernel, live HIP events over an instrumented
-                            eager pass); `step_frac_of_peak` is the whole step's model FLOPs against the same peak
-  bf16_throughput_mode .... plain bf16 storage + MFMA (what configs[1] literally names): faster, but ~1 % of the codebook
-                            indices differ from the reference -- reported with that measured agreement, never as `value`
-  f16mx_hd_mode ........... opt-in: f16mx_hb with the decoder's forward on fp16 operands too -- indices still bit-exact, reconstruction
-                            fp16-grade (AT the 1e-3 tolerance, not safely inside it), reported with its measured errors, never as `value`
-  parity_b16, parity_b64 .. the headline mode on the B = 16 golden (8 000 codebook rows, smallest reference top-2 gap 6.9e-6) and on
-                            the B = 64 golden -- the timed workload itself, run by the real reference (32 000 rows, 4.2e-6)
-  parity .................. per mode: codebook-index agreement and z / recon / loss errors MEASURED IN THIS RUN on the
-                            default-config golden made by the real reference (tests/golden/g3_speech.npz)
-  north_star .............. the mode that carries the parity claim (bit-exact indices, 1e-3 forward): its throughput,
-                            x CPU, kernel roofline against ITS structural peak, and its parity numbers
-  bf16x3_hb_parity_mode ... the stricter alternative: bf16x3 forward (6e-6: 2.3x fewer flipped near-ties than f16mx, none in the goldens)
-                            + one bf16 MFMA per backward product
-  f32_parity_mode, bf16x3_parity_mode, script_loop_mode, vq_stress, rir_config, echoed_config ... secondary lines
+OUTPUT (round 4): rank 0 prints ONE COMPACT JSON line last (< 6 KB, asserted by tests/test_bench_line_cpu.py): the contract's
+fields plus `roofline`, `cpu_baseline`, one-number parity summaries (`parity_headline`), a small per-mode table and the
+secondary configs as a few numbers each.  Everything else -- the full per-mode blocks, every parity dict, the per-family
+kernel timings -- goes to `bench_detail.json` next to this file (and to gpurun_out/ when that directory exists); round 3's
+single 20 KB line overflowed the driver's 8 KB capture and the round went unparsed.
+
+What the compact line holds (N=1):
+  value / roofline ........ the headline mode (--dtype, default x3mx_hb: bf16x3 forward for everything the codebook indices
+                            depend on, f16mx decoder forward, one 16-bit MFMA per backward product -- the fastest mode that
+                            returns EVERY index of EVERY reference golden), hipGraph replay; `roofline` is KERNEL-ONLY (the
+                            conv family with the largest share of the step, live HIP events over an instrumented eager pass
+                            of the same steps) against the structural peak of that family's arithmetic AND against the
+                            hardware's dense 16-bit peak; `step_frac_of_peak` is the whole step's model FLOPs likewise
+  parity_headline ......... index mismatches / rows of the headline mode on the goldens the REAL reference made: speech B = 2,
+                            16, 64 (the timed workload itself) and RIR / echoed at their per-GPU batch of 32
+  modes ................... spectrograms/s, ms/step, x CPU and golden index mismatches of every user-selectable mode; the
+                            f32 row is the figure AT THE REFERENCE'S OWN PRECISION
   cpu_baseline ............ the oracle port timed on the host cores (B=4, BASELINE configs[0])
+  rccl (N>1) .............. world, backend, all-reduce bytes / ms (HIP events around the collective alone) / bus GB/s,
+                            per-rank ms_per_step min / max, ranks_bit_identical (64-bit checksum of the flat buffers)
 """
 import argparse
 import json
@@ -42,51 +42,33 @@ for _p in (ROOT, PKG, os.path.join(PKG, "src"), os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
+LINE_LIMIT = 6000                 # bytes of the final stdout line (the driver's capture keeps 8 KB)
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 matrix rate (= vector rate)
-BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (NOT the 2:1-sparsity headline)
-# Peak of ALGORITHMIC FLOP/s per mode.  bf16x3 issues three bf16 MFMAs per algorithmic product (hi*hi + hi*lo +
-# lo*hi), so its structural ceiling is a third of the bf16 matrix peak; f16mx issues one fp16 MFMA plus one block-scaled
-# fp8 MFMA of the same duration per product: half of the fp16 (= bf16) matrix peak.
-# f16mx_hb: the forward third of the FLOPs at f16mx's two units per product, the backward two thirds at one fp16 MFMA per
-# product -> 1 / ((1/3) / 1250 + (2/3) / 2500) = 1875 TFLOP/s for the WHOLE step; each kernel family is judged against the
-# peak of its own arithmetic (FAMILY_PEAK).
-PEAK = {"f32": F32_MFMA_PEAK_TFLOPS, "bf16": BF16_MFMA_PEAK_TFLOPS, "bf16x3": BF16_MFMA_PEAK_TFLOPS / 3.0,
-        "f16mx": BF16_MFMA_PEAK_TFLOPS / 2.0, "f16mx_hb": 1875.0, "f16mx_hd": 2200.0, "bf16x3_hb": 1500.0}
-FAMILY_PEAK = {"conv1d_f32_kernel": ("f32", F32_MFMA_PEAK_TFLOPS), "conv1d_wgrad_f32_kernel": ("f32", F32_MFMA_PEAK_TFLOPS),
-               "conv1d_bf16x3_kernel": ("bf16x3", BF16_MFMA_PEAK_TFLOPS / 3.0), "conv1d_wgrad_bf16x3_kernel": ("bf16x3", BF16_MFMA_PEAK_TFLOPS / 3.0),
-               "conv1d_f16mx_kernel": ("f16mx", BF16_MFMA_PEAK_TFLOPS / 2.0), "conv1d_wgrad_f16mx_kernel": ("f16mx", BF16_MFMA_PEAK_TFLOPS / 2.0)}
-PEAK_NOTE = {"f32": "exact-fp32 MFMA peak 157.3 TFLOP/s", "bf16": "dense bf16 (= fp16) MFMA peak 2500 TFLOP/s",
-             "bf16x3": "2500/3 = 833.3 TFLOP/s algorithmic: three bf16 MFMAs per product",
-             "f16mx": "2500/2 = 1250 TFLOP/s algorithmic: one fp16 MFMA + one block-scaled fp8 MFMA of equal duration per product",
-             "f16mx_hb": "whole step 1875 TFLOP/s = 1 / ((1/3)/1250 + (2/3)/2500): f16mx forward, one fp16 MFMA per backward product",
-             "bf16x3_hb": "whole step 1500 TFLOP/s = 1 / ((1/3)/833 + (2/3)/2500): bf16x3 forward, one bf16 MFMA per backward product",
-             "f16mx_hd": "whole step 2200 TFLOP/s = 1 / (0.136/1250 + 0.864/2500): only the encoder's forward (13.6 of 99.95 GFLOP) at two units"}
-CONV_FAMILIES = {"f32": ("conv1d_f32_kernel", "conv1d_wgrad_f32_kernel"),
-                 "bf16": ("conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel", "conv1d_wgrad_bf16_v2_kernel"),
-                 "bf16x3": ("conv1d_bf16x3_kernel", "conv1d_wgrad_bf16x3_kernel"),
-                 "f16mx": ("conv1d_f16mx_kernel", "conv1d_wgrad_f16mx_kernel"),
-                 "f16mx_hb": ("conv1d_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel"),
-                 "f16mx_hd": ("conv1d_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel"),
-                 "bf16x3_hb": ("conv1d_bf16x3_kernel", "conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel",
-                               "conv1d_wgrad_bf16_v2_kernel")}
-MODE_TEXT = {"bf16": "bf16 storage + bf16 MFMA, fp32 accumulate / VQ / losses / master weights",
-             "bf16x3": "split-bf16 (hi+lo planes, 3 bf16 MFMAs per product, fp32 accumulate)",
-             "f16mx": "fp16 plane + fp8 (hi,lo) plane: one fp16 MFMA + one block-scaled fp8 MFMA per product, fp32 accumulate",
-             "f16mx_hb": "f16mx forward (fp32-grade outputs) + fp16 backward (one fp16 MFMA per product under a loss scale, fp32 accumulate)",
-             "f16mx_hd": "f16mx encoder + quantiser forward, fp16 decoder forward, fp16 backward (opt-in)",
-             "bf16x3_hb": "bf16x3 forward (three bf16 MFMAs per product) + bf16 backward (one bf16 MFMA per product on the hi planes)",
-             "f32": "fp32 storage + exact-fp32 MFMA"}
-PARITY_MODES = ("f16mx_hb", "bf16x3_hb", "f16mx", "bf16x3")  # modes whose parity is bit-exact indices / <=1e-3 forward; the fastest carries the claim
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (NOT the 2:1-sparsity headline)
+# Matrix-pipe units per ALGORITHMIC product, (encoder-side forward, decoder forward, backward): bf16x3 issues three bf16
+# MFMAs per product (hi*hi + hi*lo + lo*hi), f16mx one fp16 MFMA plus one block-scaled fp8 MFMA of the same duration, the
+# "hb" backward ONE 16-bit MFMA.  A mode's structural peak for the whole step is 2500 * flops / sum(flops_part * units_part).
+UNITS = {"x3mx_hb": (3, 2, 1), "f16mx_hb": (2, 2, 1), "bf16x3_hb": (3, 3, 1), "bf16": (1, 1, 1)}
+FAMILY_PEAK = {"conv1d_f32_kernel": F32_MFMA_PEAK_TFLOPS, "conv1d_wgrad_f32_kernel": F32_MFMA_PEAK_TFLOPS,
+               "conv1d_bf16x3_kernel": BF16_MFMA_PEAK_TFLOPS / 3.0, "conv1d_wgrad_bf16x3_kernel": BF16_MFMA_PEAK_TFLOPS / 3.0,
+               "conv1d_f16mx_kernel": BF16_MFMA_PEAK_TFLOPS / 2.0, "conv1d_wgrad_f16mx_kernel": BF16_MFMA_PEAK_TFLOPS / 2.0}
+FAMILY_NOTE = {157.3: "exact-fp32 MFMA 157.3", 2500.0: "dense 16-bit MFMA 2500", 2500.0 / 3: "2500/3: three bf16 MFMAs per product",
+               1250.0: "2500/2: one fp16 + one equal-length block-scaled fp8 MFMA per product"}
+CONV_FAMILIES = ("conv1d_f32_kernel", "conv1d_wgrad_f32_kernel", "conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel",
+                 "conv1d_wgrad_bf16_v2_kernel", "conv1d_bf16x3_kernel", "conv1d_wgrad_bf16x3_kernel", "conv1d_f16mx_kernel",
+                 "conv1d_wgrad_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel")
+MODE_TEXT = {"x3mx_hb": "bf16x3 encoder+pre-VQ forward, f16mx decoder forward, one bf16/fp16 MFMA per backward product",
+             "f16mx_hb": "f16mx forward (fp16 + block-scaled fp8 MFMA per product), one fp16 MFMA per backward product",
+             "bf16x3_hb": "bf16x3 forward (three bf16 MFMAs per product), one bf16 MFMA per backward product",
+             "bf16": "bf16 storage + one bf16 MFMA per product (throughput mode: ~1% of the indices differ)",
+             "f32": "fp32 storage + exact-fp32 MFMA (the reference's own precision)"}
+ALL_MODES = ("x3mx_hb", "f16mx_hb", "bf16x3_hb", "f32", "bf16")
 SPEECH_CFG = (201, 1024, 128, 3, 1024, 0.25, 1024)          # scripts/train_speech.py:152-153
 RIR_CFG = (500, 1024, 64, 2, 64, 0.25, 1024)                # scripts/train_rir.py:147-149
 
 
-def algorithmic_gflop_per_spectrogram(cfg, L, out_channels=None):
-    """SURVEY 8(d): train = 3*F_conv - (no dgrad into the input) + VQ distance GEMM (forward only)."""
+def conv_gflop_parts(cfg, L, out_channels=None):
+    """Forward conv GFLOP per spectrogram of (encoder + pre-VQ conv, decoder); SURVEY App. A.6."""
     c, h, d, r, rh, _, k = cfg
     oc = c if out_channels is None else out_channels
     enc1 = 2 * c * h * 3 * L
@@ -95,12 +77,110 @@ def algorithmic_gflop_per_spectrogram(cfg, L, out_channels=None):
     dec1 = 2 * d * h * 3 * L
     up = 2 * h * h * 3 * L
     last = 2 * h * oc * 3 * L
-    f_conv = enc1 + 2 * r * res + pre + dec1 + 2 * up + last
-    return (3 * f_conv - enc1 + 2 * L * k * d) / 1e9
+    return (enc1 + r * res + pre) / 1e9, (dec1 + r * res + 2 * up + last) / 1e9, enc1 / 1e9
+
+
+def algorithmic_gflop_per_spectrogram(cfg, L, out_channels=None):
+    """SURVEY 8(d): train = 3*F_conv - (no dgrad into the input) + VQ distance GEMM (forward only)."""
+    enc, dec, enc1 = conv_gflop_parts(cfg, L, out_channels)
+    return 3 * (enc + dec) - enc1 + 2 * L * cfg[6] * cfg[2] / 1e9
+
+
+def step_peak_tflops(mode, cfg=SPEECH_CFG, L=500, out_channels=None):
+    """Structural peak of ALGORITHMIC TFLOP/s for the whole step in `mode` (see UNITS)."""
+    if mode == "f32":
+        return F32_MFMA_PEAK_TFLOPS
+    enc, dec, enc1 = conv_gflop_parts(cfg, L, out_channels)
+    ue, ud, ub = UNITS[mode]
+    bwd = 2 * (enc + dec) - enc1
+    return BF16_MFMA_PEAK_TFLOPS * (enc + dec + bwd) / (enc * ue + dec * ud + bwd * ub)
+
+
+def _r(x, digits=5):
+    """Shorten a number for the compact line (5 significant digits)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (digits, float(x)))
+    except (TypeError, ValueError):
+        return x
+
+
+def _idx(p):
+    return None if not p or "idx_total" not in p else "%d/%d" % (p["idx_mismatches"], p["idx_total"])
+
+
+def compact_line(d):
+    """The final stdout line from the full result `d` (what bench_detail.json holds).  Pure: tests call it on canned
+    results.  Contract fields first; everything is a few numbers, never a nested per-mode block."""
+    out = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _r(out["value"], 6), _r(out["ms_per_step"], 6)
+    out["config"] = dict(d["config"])
+    out["config"]["algorithmic_gflop_per_spectrogram"] = _r(out["config"].get("algorithmic_gflop_per_spectrogram"))
+    for k in ("launch", "allreduce_calls_per_step", "fp16_range_flag", "skipped_steps"):
+        if k in d:
+            out[k] = d[k]
+    for k in ("final_loss", "model_tflops", "step_frac_of_peak", "step_peak_tflops", "step_frac_of_dense_16bit_peak",
+              "other_kernels_share", "gpu_over_cpu"):
+        if k in d:
+            out[k] = _r(d[k])
+    if "roofline" in d:
+        out["roofline"] = {k: _r(v) for k, v in d["roofline"].items()}
+    if "cpu_baseline" in d:
+        out["cpu_baseline"] = {k: _r(v) for k, v in d["cpu_baseline"].items()}
+    if d.get("parity"):
+        ph = {}
+        for key, name in (("b2", "speech_b2"), ("b16", "speech_b16"), ("b64", "speech_b64_the_timed_workload"),
+                          ("rir_b2", "rir_b2"), ("rir_b32", "rir_b32"), ("echoed_b32", "echoed_b32")):
+            p = d["parity"].get(key)
+            if p:
+                ph[name] = _idx(p) if "idx_total" in p else "recon %.1e" % p["recon_rel_max"]
+        b64 = d["parity"].get("b64") or d["parity"].get("b2") or {}
+        for k in ("z_rel_max", "recon_rel_max", "vq_loss_rel", "recon_error_rel", "grad_rel_max", "grad_rel_l2_median"):
+            if k in b64:
+                ph[k] = _r(b64[k], 3)
+        ph["is"] = "index mismatches / codebook rows vs goldens made by the real reference; rel errors on the largest speech golden"
+        out["parity_headline"] = ph
+    if d.get("modes"):
+        cpu = (d.get("cpu_baseline") or {}).get("value")
+        out["modes"] = {}
+        for m, r in d["modes"].items():
+            row = {"value": _r(r["value"], 4), "ms": _r(r["ms_per_step"], 4), "step_frac": _r(r["step_frac_of_peak"], 3)}
+            if cpu:
+                row["x_cpu"] = _r(r["value"] / cpu, 3)
+            if r.get("parity_b2"):
+                row["idx_b2"] = _idx(r["parity_b2"])
+            if "roofline" in r:
+                row["kernel_frac"] = _r(r["roofline"]["frac"], 3)
+            out["modes"][m] = row
+        if "f32" in d["modes"]:
+            out["modes"]["f32"]["is"] = "the reference's own precision"
+    sec = {}
+    for key in ("rir_config", "echoed_config"):
+        if key in d:
+            r = d[key]
+            sec[key.split("_")[0] + "_b32"] = {"value": _r(r["value"], 4), "ms": _r(r["ms_per_step"], 4)}
+    if "vq_stress" in d:
+        v = d["vq_stress"]
+        sec["vq_stress"] = {"ms": _r(v["ms"], 4), "frac_f32_peak": _r(v["frac"], 3), "idx_exact_on_sample": v["idx_bit_exact_on_sample"]}
+    if "script_loop_mode" in d:
+        v = d["script_loop_mode"]
+        sec["script_loop"] = {"value": _r(v["value"], 4), "vs_trainer_eager": _r(v.get("vs_trainer_eager"), 3)}
+    if sec:
+        out["configs"] = sec
+    for k in ("grad_exchange", "rccl"):
+        if k in d:
+            out[k] = json.loads(json.dumps(d[k]), parse_float=lambda s: _r(float(s)))
+    if "detail_file" in d:
+        out["detail_file"] = d["detail_file"]
+    return out
 
 
 def cpu_baseline(seconds_budget=20.0):
     """The oracle restatement (kind "port") timed on this host: speech ctor, B=4 (BASELINE configs[0])."""
+    import numpy as np
+    import torch
     from oracle import vqvae_oracle as O
     # the GPU box exposes 256 logical CPUs but gives a 1-GPU job a 16-CPU share; oversubscribing is 100x slower
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -115,14 +195,14 @@ def cpu_baseline(seconds_budget=20.0):
     tr.step(x)                                   # warm-up
     tr.step(x)
     times, t_end = [], time.time() + seconds_budget
-    while len(times) < 3 or (time.time() < t_end and len(times) < 20):
+    while len(times) < 3 or (time.time() < t_end and len(times) < 60):
         t0 = time.time()
         tr.step(x)
         times.append(time.time() - t0)
     med = float(np.median(times))
     return {"value": 4.0 / med, "unit": "spectrograms/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps of the CPU oracle (same ATen op sequence as the reference), speech ctor, "
-                      "B=4 x (201,500) fp32, jitter on, Adam; median %.3f s/step" % (len(times), med)}
+            "sample": "%d train steps of the CPU oracle (the reference's ATen op sequence), speech ctor, B=4 x (201,500) fp32, "
+                      "jitter on, Adam; median %.3f s/step" % (len(times), med)}
 
 
 def main():
@@ -133,19 +213,21 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU")
     ap.add_argument("--config", default="speech", choices=["speech", "rir", "echoed"],
                     help="speech = BASELINE configs[1] (the headline); rir = configs[2]; echoed = configs[4]")
-    ap.add_argument("--dtype", default="f16mx_hb", choices=["bf16", "f32", "bf16x3", "f16mx", "f16mx_hb", "f16mx_hd", "bf16x3_hb"],
-                    help="f16mx_hb (default): the fastest mode that holds the north star's parity -- f16mx forward (fp16 + "
-                         "block-scaled fp8 MFMA per product), fp16 backward; f16mx: the cross terms in the backward too; bf16x3_hb: "
-                         "bf16x3 forward, bf16 backward; bf16x3: "
-                         "split-bf16 parity mode (3 bf16 MFMAs per product); f32: exact-fp32 MFMA; bf16: throughput mode (bf16 "
-                         "storage/MFMA; ~1 %% of the codebook indices differ)")
+    ap.add_argument("--dtype", default="x3mx_hb", choices=list(ALL_MODES),
+                    help="x3mx_hb (default): bf16x3 forward for the encoder side (every golden index exact), f16mx decoder forward, "
+                         "16-bit backward; f16mx_hb: f16mx forward everywhere (2-3 %% faster; flips reference near-ties below ~4e-6); "
+                         "bf16x3_hb: bf16x3 forward everywhere; f32: exact-fp32 MFMA; bf16: throughput mode (~1 %% of the indices differ)")
     ap.add_argument("--no-secondary", "--no-f32-line", dest="no_secondary", action="store_true",
-                    help="only the headline line (skip parity modes, script loop, VQ stress, rir / echoed configs)")
+                    help="only the headline line (skip the other modes, script loop, VQ stress, rir / echoed configs)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the golden parity measurements")
     args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -163,13 +245,20 @@ def main():
     # (the identity there) -- a rehearsal of the N > 1 flow (process group, broadcast, capture next to the watchdog thread,
     # collectives between graph replays and Adam) on a single GPU; tests/test_rccl_gpu.py runs it
     force_pg = os.environ.get("ALVQ_FORCE_COLLECTIVE", "0") != "0"
-    if world > 1 or force_pg:
+    multi = world > 1 or force_pg
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # one process per GPU: every rank must be driving ITS card (a launcher that forgot LOCAL_RANK would put all ranks on
+        # card 0 and report N times one GPU's rate)
+        if backend == "nccl":
+            assert torch.cuda.current_device() == int(os.environ.get("LOCAL_RANK", "0")), \
+                "rank %d drives cuda:%d, LOCAL_RANK says %s" % (rank, torch.cuda.current_device(), os.environ.get("LOCAL_RANK"))
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
 
     from acoustic_locating_vq_vae import _native as N
     from acoustic_locating_vq_vae import _ops
@@ -177,7 +266,7 @@ def main():
     from acoustic_locating_vq_vae.train_step import Trainer
 
     def barrier():
-        if world > 1 or force_pg:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -209,44 +298,73 @@ def main():
         dt = time.perf_counter() - t0
         if timer is not None:
             timer.__exit__()
-        if world > 1 or force_pg:
+        per_rank = None
+        if multi:
             t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            gathered = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            per_rank = [float(g.item()) for g in gathered]
+            dt = max(per_rank)                               # the contract's MAX over ranks
         last = float(out[0])
         assert np.isfinite(last), "non-finite loss"
-        return dt, last, (timer.summary() if timer is not None else None)
+        return dt, last, (timer.summary() if timer is not None else None), per_rank
 
-    def roofline(summ, dtype):
-        # the dominant kernel = the conv kernel with the largest share of the timed region
-        fam = max((f for f in CONV_FAMILIES[dtype] if f in summ), key=lambda f: summ[f][1])
+    def roofline(summ):
+        # the dominant kernel = the conv family with the largest share of the timed region
+        fam = max((f for f in CONV_FAMILIES if f in summ), key=lambda f: summ[f][1])
         n, secs, flops = summ[fam]
         ach = flops / secs / 1e12
-        arith, peak = FAMILY_PEAK.get(fam, ("bf16", BF16_MFMA_PEAK_TFLOPS))     # the kernel's own arithmetic (fp16 = bf16 rate)
-        note = PEAK_NOTE[arith] if arith in PEAK_NOTE else PEAK_NOTE["bf16"]
+        peak = FAMILY_PEAK.get(fam, BF16_MFMA_PEAK_TFLOPS)     # the family's own arithmetic (fp16 = bf16 rate)
         traffic, source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = tj.get(fam)
-            source = "NOT measured in this run: profiles/traffic.json (%s)" % tj.get("_source", "rocprofv3 --pmc passes, tools/profile_bench.sh")
-        return {"bound": "mfma", "scope": "kernel-only (dominant conv kernel, not the whole step)", "kernel": fam,
-                "achieved": ach, "peak": peak, "peak_is": note, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": traffic, "traffic_source": source, "launches": n,
-                "avg_launch_ms": 1e3 * secs / n, "algorithmic_gflop_per_launch": flops / n / 1e9}
+            source = "NOT measured in this run: profiles/traffic.json (rocprofv3 --pmc passes, tools/profile_bench.sh)"
+        return {"bound": "mfma", "scope": "kernel-only: the conv family with the largest share of the step", "kernel": fam,
+                "achieved": ach, "peak": peak, "peak_is": FAMILY_NOTE.get(peak, "dense 16-bit MFMA 2500") + " TFLOP/s",
+                "unit": "TFLOP/s", "frac": ach / peak, "frac_of_dense_16bit_peak": ach / BF16_MFMA_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_source": source, "launches": n, "avg_launch_ms": 1e3 * secs / n,
+                "algorithmic_gflop_per_launch": flops / n / 1e9}
 
     def families(summ, steps):
         return {k: {"launches": v[0], "ms_per_step": 1e3 * v[1] / steps, "tflops": (v[2] / v[1] / 1e12) if v[1] > 0 else None}
                 for k, v in summ.items()}
 
-    def run_config(kind, dtype, B, steps, warmup, graph=True, timer=True, grad_buckets=None):
+    def rccl_block(trainer):
+        """The collective alone: HIP events around all-reduces of a buffer the size of the flat gradient buffer (median of
+        10), and a 64-bit checksum of every rank's flat parameter buffer after the last step (they must be identical)."""
+        n = trainer.buffers.grad.numel()
+        scratch = torch.zeros(n, device="cuda")
+        for _ in range(2):
+            dist.all_reduce(scratch)
+        times = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            e0.record()
+            dist.all_reduce(scratch)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+        ms = float(np.median(times))
+        chk = trainer.buffers.flat.view(torch.int32).to(torch.int64).sum().reshape(1)
+        got = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(got, chk)
+        sums = [int(g.item()) for g in got]
+        return {"world": world, "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "nranks_seen": dist.get_world_size(),
+                "allreduce_bytes": 4 * n, "allreduce_ms": ms, "allreduce_ms_min": float(min(times)),
+                "bus_GBps": (2.0 * (world - 1) / world) * 4 * n / (ms * 1e-3) / 1e9 if world > 1 else 0.0,
+                "ranks_bit_identical": len(set(sums)) == 1, "flat_checksum": sums[0]}
+
+    def run_config(kind, dtype, B, steps, warmup, graph=True, timer=True, grad_buckets=None, want_rccl=False):
         """One (config, mode) measurement on a fresh model: K timed steps (graph replay when captured); the per-kernel
         durations behind `roofline` come from an instrumented eager pass of the same steps right after, because HIP
         events cannot bracket kernels inside a replay."""
         _ops.set_compute_dtype(dtype)
         np.random.seed(1234 + rank)                  # jitter: per-rank numpy stream (SURVEY 8e)
         model, cfg, gf = make(kind)
-        trainer = Trainer(model, kind, grad_buckets=grad_buckets)
+        trainer = Trainer(model, kind, grad_buckets=grad_buckets, range_check_every=0)
         g = torch.Generator(device="cuda")
         g.manual_seed(100 + rank)
         raw = torch.randn(B, 201, 500, device="cuda", generator=g)      # synthetic spectrogram batch, resident in HBM
@@ -259,30 +377,41 @@ def main():
             except Exception as exc:                           # fall back to eager launches, and say so
                 launch = "eager (capture failed: %s)" % (str(exc).splitlines()[0][:120],)
                 trainer._graph = None
-        if dtype.startswith("f16mx"):
+        if _ops.has_fp16_range(dtype):
             N.f16mx_range_flag(reset=True)
-        elapsed, loss, summ = measure(trainer, raw, wiener, steps, warmup, timer and trainer._graph is None)
+            trainer.opt.skipped_steps(reset=True)
+        elapsed, loss, summ, per_rank = measure(trainer, raw, wiener, steps, warmup, timer and trainer._graph is None)
+        value = world * B * steps / elapsed
+        oc = 1 if kind == "rir" else None
+        peak = step_peak_tflops(dtype, cfg, 201 if kind == "rir" else 500, oc) if kind != "echoed" else None
+        res = {"value": value, "unit": "spectrograms/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+               "dtype": dtype, "launch": launch, "model_tflops": value * gf / 1e3, "final_loss": loss,
+               "allreduce_calls_per_step": (0 if not multi else (2 if trainer._buckets else 1))}
+        if peak:
+            res["step_peak_tflops"] = peak
+            res["step_frac_of_peak"] = value * gf / 1e3 / world / peak
+            res["step_frac_of_dense_16bit_peak"] = value * gf / 1e3 / world / (BF16_MFMA_PEAK_TFLOPS if dtype != "f32" else F32_MFMA_PEAK_TFLOPS)
+        if per_rank is not None:
+            res["per_rank_ms_per_step"] = {"min": 1e3 * min(per_rank) / steps, "max": 1e3 * max(per_rank) / steps}
+        if _ops.has_fp16_range(dtype):
+            # 0 / 0 = no value entering or produced inside the fp16-range formats saturated during the timed steps, no step skipped
+            res["skipped_steps"] = trainer.opt.skipped_steps(reset=True)
+            res["fp16_range_flag"] = N.f16mx_range_flag(reset=True)
+        if want_rccl and multi:
+            res["rccl"] = rccl_block(trainer)
         if summ is None and timer:
             g_saved, gl_saved = trainer._graph, getattr(trainer, "_graph_late", None)
             trainer._graph = None
-            _, _, summ = measure(trainer, raw, wiener, min(steps, 10), 1, True)
-            trainer._graph, trainer._graph_late = g_saved, gl_saved
             summ_steps = min(steps, 10)
+            _, _, summ, _ = measure(trainer, raw, wiener, summ_steps, 1, True)
+            trainer._graph, trainer._graph_late = g_saved, gl_saved
         else:
             summ_steps = steps
-        value = world * B * steps / elapsed
-        res = {"value": value, "unit": "spectrograms/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-               "dtype": dtype, "launch": launch, "model_tflops": value * gf / 1e3,
-               "step_frac_of_peak": value * gf / 1e3 / world / PEAK[dtype], "final_loss": loss,
-               "allreduce_calls_per_step": (0 if (world == 1 and not force_pg) else (2 if trainer._buckets else 1))}
-        if dtype.startswith("f16mx"):
-            # 0 = no value entering or produced inside the fp16-range formats saturated during the timed steps
-            res["fp16_range_flag"] = N.f16mx_range_flag(reset=True)
         if summ is not None:
-            res["roofline"] = roofline(summ, dtype)
+            res["roofline"] = roofline(summ)
             res["kernel_families"] = families(summ, summ_steps)
             # everything that is not a convolution / weight-gradient / VQ-argmin launch (layout conversions, split
-            # reductions, quantiser epilogues, weight packing, losses, Adam): the replayed step minus the timed families
+            # reductions, quantiser epilogues, losses, Adam): the replayed step minus the timed families
             timed = sum(v["ms_per_step"] for v in res["kernel_families"].values())
             res["other_kernels_ms_per_step"] = res["ms_per_step"] - timed
             res["other_kernels_share"] = (res["ms_per_step"] - timed) / res["ms_per_step"]
@@ -291,90 +420,77 @@ def main():
         return res, cfg, gf
 
     def parity(mode, tag="speech"):
-        """The current build's parity on the default-config golden (2 x (201,500), closed-form weights; made by the
-        real reference; tag "speech_b16": the same at B = 16, 8 000 codebook rows).  The oracle package supplies the
-        weight/input generators only -- a checker, never timed."""
+        """The current build's parity on a golden made by the real reference (closed-form weights; tests/golden/g3_<tag>.npz).
+        The oracle package supplies the weight / input generators only -- a checker, never timed."""
         import g3_cases
         _ops.set_compute_dtype(mode)
         r = g3_cases.run(tag)
         keep = ("idx_total", "idx_mismatches", "idx_agree", "mismatch_gap_max", "slice_elems", "z_rel_max", "z_rel_l2", "z_sum_rel",
                 "recon_rel_max", "recon_rel_l2", "recon_sum_rel", "vq_loss_rel", "recon_error_rel", "grad_rel_max",
-                "grad_rel_l2_median", "grad_sum_rel_max", "encoder_grad_rel_max")
+                "grad_rel_l2_median", "grad_rel_l2_max", "grad_sum_rel_max", "encoder_grad_rel_max")
         out = {k: r[k] for k in keep if k in r}
-        out["golden"] = "tests/golden/g3_%s.npz (%s ctor, B=%d, made by the reference)" % (
-            tag, tag.split("_")[0], int(tag[-2:]) if tag[-2:].isdigit() else 2)
+        out["golden"] = "tests/golden/g3_%s.npz" % tag
         return out
 
     kind, B = args.config, args.batch
     head, cfg, gf = run_config(kind, args.dtype, B, args.steps, args.warmup, graph=not args.no_graph,
-                               timer=not args.no_kernel_timer)
-    line = None
+                               timer=not args.no_kernel_timer, want_rccl=True)
+    full = None
     if rank == 0:
-        line = {
+        full = {
             "metric": "spectrograms/sec (train step), %s VQ-VAE default config" % ("echoed-speech" if kind == "echoed" else kind),
             "value": head["value"], "unit": "spectrograms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s VQ-VAE train step (fwd+bwd+Adam), ctor %s, B=%d per GPU x (%s), %s, jitter %s"
-                                   % (kind, list(cfg), B, "500,201" if kind == "rir" else "201,500", MODE_TEXT[args.dtype],
-                                      "off" if kind == "rir" else "on"),
+            "config": {"workload": "%s VQ-VAE train step (fwd+bwd+Adam), ctor %s, B=%d per GPU x (%s), jitter %s; %s"
+                                   % (kind, list(cfg), B, "500,201" if kind == "rir" else "201,500",
+                                      "off" if kind == "rir" else "on", MODE_TEXT[args.dtype]),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "algorithmic_gflop_per_spectrogram": gf},
-            "model_tflops": head["model_tflops"], "step_frac_of_peak": head["step_frac_of_peak"],
-            "final_loss": head["final_loss"], "launch": head["launch"],
-            "allreduce_calls_per_step": head["allreduce_calls_per_step"],
         }
-        for k in ("roofline", "kernel_families", "other_kernels_ms_per_step", "other_kernels_share", "fp16_range_flag"):
+        for k in ("model_tflops", "step_peak_tflops", "step_frac_of_peak", "step_frac_of_dense_16bit_peak", "final_loss", "launch",
+                  "allreduce_calls_per_step", "roofline", "kernel_families", "other_kernels_ms_per_step", "other_kernels_share",
+                  "fp16_range_flag", "skipped_steps", "per_rank_ms_per_step", "rccl"):
             if k in head:
-                line[k] = head[k]
+                full[k] = head[k]
+        if "rccl" in full and "per_rank_ms_per_step" in full:
+            full["rccl"]["per_rank_ms_per_step"] = full.pop("per_rank_ms_per_step")
 
     secondary = not args.no_secondary
-    if (world > 1 or force_pg) and secondary and kind != "echoed":
+    if multi and secondary and kind != "echoed":
         # gradient exchange, measured both ways on this node: the north star's single all-reduce (the default) and the
         # two-span variant whose first span overlaps the encoder's backward
         alt, _, _ = run_config(kind, args.dtype, B, max(3, min(10, args.steps)), 2, graph=not args.no_graph, timer=False,
                                grad_buckets=2)
         if rank == 0:
-            line["grad_exchange"] = {
+            full["grad_exchange"] = {
                 "default": {"allreduce_calls_per_step": head["allreduce_calls_per_step"], "value": head["value"],
                             "ms_per_step": head["ms_per_step"]},
                 "two_spans": {"allreduce_calls_per_step": alt["allreduce_calls_per_step"], "value": alt["value"],
                               "ms_per_step": alt["ms_per_step"]}}
 
+    modes = {}
     if kind == "speech" and secondary:
-        modes = {}
-        for mode in ("f16mx_hb", "bf16x3_hb", "f16mx", "bf16x3", "f32", "bf16", "f16mx_hd"):
+        for mode in ALL_MODES:
             if mode == args.dtype:
                 modes[mode] = head
                 continue
             steps2 = max(3, min(5 if mode == "f32" else 10, args.steps))
-            modes[mode], _, _ = run_config("speech", mode, B, steps2, 2, graph=not args.no_graph,
-                                           timer=not args.no_kernel_timer)
+            modes[mode], _, _ = run_config("speech", mode, B, steps2, 2, graph=not args.no_graph, timer=not args.no_kernel_timer)
         if rank == 0:
-            for mode, key in (("f32", "f32_parity_mode"), ("bf16x3", "bf16x3_parity_mode"), ("f16mx", "f16mx_parity_mode"),
-                              ("f16mx_hb", "f16mx_hb_parity_mode"), ("bf16x3_hb", "bf16x3_hb_parity_mode"), ("bf16", "bf16_throughput_mode"),
-                              ("f16mx_hd", "f16mx_hd_mode")):
-                if mode != args.dtype:
-                    line[key] = {k: v for k, v in modes[mode].items() if k != "kernel_families"}
-            ns_mode = max(PARITY_MODES, key=lambda m: modes[m]["value"])
-            line["_ns_src"] = (ns_mode, modes[ns_mode])
+            full["modes"] = {m: dict(r, what=MODE_TEXT[m]) for m, r in modes.items()}
 
     if rank == 0 and world == 1 and kind == "speech" and not args.no_parity:
-        line["parity"] = {m: parity(m) for m in (["f16mx_hb", "bf16x3_hb", "f16mx", "bf16x3", "f32", "bf16", "f16mx_hd"] if secondary else [args.dtype])}
-        line["parity_b16"] = {args.dtype: parity(args.dtype, "speech_b16")}     # 8 000 rows, smallest top-2 gap 6.9e-6
-        line["parity_b64"] = {args.dtype: parity(args.dtype, "speech_b64")}     # the timed workload itself: 32 000 rows, 4.2e-6
+        # parity of the HEADLINE mode on every golden the real reference made, and of each other mode on the B = 2 one
+        par = {"b2": parity(args.dtype), "b16": parity(args.dtype, "speech_b16"), "b64": parity(args.dtype, "speech_b64")}
+        if secondary:
+            par["rir_b2"] = parity(args.dtype, "rir")
+            par["rir_b32"] = parity(args.dtype, "rir_b32")
+            par["echoed_b32"] = parity(args.dtype, "echoed_b32")
+            for m in modes:
+                full["modes"][m]["parity_b2"] = par["b2"] if m == args.dtype else parity(m)
+        full["parity"] = par
         _ops.set_compute_dtype(args.dtype)
-        if "f16mx_hd_mode" in line and "f16mx_hd" in line["parity"]:
-            h = line["parity"]["f16mx_hd"]
-            line["f16mx_hd_mode"]["parity_note"] = (
-                "opt-in, not counted among the parity-holding modes: %d of %d codebook indices differ (the encoder side is "
-                "f16mx_hb's bit for bit), reconstruction rel-max %.2g -- fp16-grade, inside 1e-3 here but measured up to 1.3e-3 on "
-                "small models (tests/test_f16mx_hd_gpu.py)" % (h["idx_mismatches"], h["idx_total"], h["recon_rel_max"]))
-        if "bf16_throughput_mode" in line and "bf16" in line["parity"]:
-            b = line["parity"]["bf16"]
-            line["bf16_throughput_mode"]["parity_note"] = (
-                "NOT the north-star operating point: %d of %d codebook indices differ from the reference golden, recon "
-                "rel-L2 %.2g" % (b["idx_mismatches"], b["idx_total"], b["recon_rel_l2"]))
 
     if rank == 0 and world == 1 and kind == "speech" and secondary:
         # what scripts/train_speech.py itself gets when its imports resolve to this build: the script's own loop body
@@ -403,7 +519,7 @@ def main():
             script_step()
         torch.cuda.synchronize()
         e3 = time.perf_counter() - t0
-        line["script_loop_mode"] = {"value": B * s3 / e3, "unit": "spectrograms/s", "ms_per_step": 1e3 * e3 / s3, "steps": s3,
+        full["script_loop_mode"] = {"value": B * s3 / e3, "unit": "spectrograms/s", "ms_per_step": 1e3 * e3 / s3, "steps": s3,
                                     "dtype": args.dtype,
                                     "launch": "eager, module API + torch.optim.Adam (train_speech.py:62-74,88-91)"}
         del m2, opt2, raw
@@ -411,9 +527,9 @@ def main():
         # the Trainer without graph replay (flat buffers, HIP Adam, gradient sinks; eager launches): what the script loop
         # is to be compared with
         te, _, _ = run_config("speech", args.dtype, B, s3, 2, graph=False, timer=False)
-        line["trainer_eager_mode"] = {"value": te["value"], "unit": "spectrograms/s", "ms_per_step": te["ms_per_step"],
+        full["trainer_eager_mode"] = {"value": te["value"], "unit": "spectrograms/s", "ms_per_step": te["ms_per_step"],
                                       "steps": s3, "dtype": args.dtype, "launch": te["launch"]}
-        line["script_loop_mode"]["vs_trainer_eager"] = line["script_loop_mode"]["value"] / te["value"]
+        full["script_loop_mode"]["vs_trainer_eager"] = full["script_loop_mode"]["value"] / te["value"]
 
         # BASELINE configs[3]: the VQ argmin kernel alone, codebook 4096 x 256, N = 512 * 500 rows
         n_, k_, d_ = 256000, 4096, 256
@@ -433,7 +549,7 @@ def main():
         rows = torch.arange(0, n_, 997, device="cuda")
         ok = bool(torch.equal(idx[rows].cpu(), O.vq_distances(xs[rows].cpu(), es.cpu()).argmin(dim=1)))
         tf = 2.0 * n_ * k_ * d_ / ms / 1e9
-        line["vq_stress"] = {"workload": "alvq_vq_argmin_f32, x (256000,256) vs codebook (4096,256), N(0,1) (BASELINE configs[3])",
+        full["vq_stress"] = {"workload": "alvq_vq_argmin_f32, x (256000,256) vs codebook (4096,256), N(0,1) (BASELINE configs[3])",
                              "ms": ms, "tflops": tf, "peak": F32_MFMA_PEAK_TFLOPS, "frac": tf / F32_MFMA_PEAK_TFLOPS,
                              "rows_per_s": n_ / ms * 1e3, "idx_bit_exact_on_sample": ok, "sample_rows": int(rows.numel()),
                              "algorithmic_mbytes": (n_ * d_ * 4 + k_ * d_ * 4 + n_ * 8) / 1e6}
@@ -443,47 +559,35 @@ def main():
         # BASELINE configs[2] and [4] at their per-GPU batch (256/8 and 128/4 = 32), headline dtype, graph replay
         for cfgname, key in (("rir", "rir_config"), ("echoed", "echoed_config")):
             r, c2, gf2 = run_config(cfgname, args.dtype, 32, max(5, min(20, args.steps)), 3, graph=not args.no_graph, timer=False)
-            line[key] = {"workload": "%s train step, B=32 per GPU (BASELINE configs[%d] per-GPU share), %s"
+            full[key] = {"workload": "%s train step, B=32 per GPU (BASELINE configs[%d] per-GPU share), %s"
                                      % (cfgname, 2 if cfgname == "rir" else 4, args.dtype),
                          "value": r["value"], "unit": "spectrograms/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                          "launch": r["launch"], "model_tflops": r["model_tflops"], "algorithmic_gflop_per_spectrogram": gf2}
-            other = "bf16" if args.dtype == PARITY_MODES[0] else PARITY_MODES[0]   # the same config in the other operating point
-            r2, _, _ = run_config(cfgname, other, 32, max(5, min(20, args.steps)), 3, graph=not args.no_graph, timer=False)
-            line[key]["throughput_mode" if other == "bf16" else "parity_mode"] = {
-                "dtype": other, "value": r2["value"], "ms_per_step": r2["ms_per_step"], "model_tflops": r2["model_tflops"]}
-            if not args.no_parity:
-                # this config at this batch against the golden the real reference made; for the f16mx family the RIR golden
-                # holds the one index it flips (a 1.8e-6 reference near-tie) -- reported, not hidden
-                pr = parity(args.dtype, cfgname + "_b32")
-                line[key]["parity_b32"] = {k: pr[k] for k in ("idx_total", "idx_mismatches", "mismatch_gap_max", "z_rel_max",
-                                                               "recon_rel_l2", "recon_error_rel", "grad_rel_l2_median", "golden") if k in pr}
-                _ops.set_compute_dtype(args.dtype)
+            r2, _, _ = run_config(cfgname, "bf16", 32, max(5, min(20, args.steps)), 3, graph=not args.no_graph, timer=False)
+            full[key]["throughput_mode"] = {"dtype": "bf16", "value": r2["value"], "ms_per_step": r2["ms_per_step"],
+                                            "model_tflops": r2["model_tflops"]}
+        _ops.set_compute_dtype(args.dtype)
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-        ns_mode, ns = line.pop("_ns_src", (None, None))
-        if ns is not None:
-            # the operating point that carries the north star's parity claim, in one place
-            blk = {"mode": ns_mode, "what": MODE_TEXT[ns_mode], "value": ns["value"], "unit": "spectrograms/s",
-                   "ms_per_step": ns["ms_per_step"], "launch": ns["launch"], "step_frac_of_peak": ns["step_frac_of_peak"]}
-            if "roofline" in ns:
-                blk["roofline_frac"] = ns["roofline"]["frac"]
-                blk["roofline_peak"] = ns["roofline"]["peak_is"]
-                blk["roofline_kernel"] = ns["roofline"]["kernel"]
-                blk["roofline_achieved_tflops"] = ns["roofline"]["achieved"]
-            if "cpu_baseline" in line:
-                blk["x_cpu"] = ns["value"] / line["cpu_baseline"]["value"]
-            if "parity" in line and ns_mode in line["parity"]:
-                blk["parity"] = line["parity"][ns_mode]
-            for key in ("parity_b16", "parity_b64"):
-                if ns_mode in line.get(key, {}):
-                    blk[key] = line[key][ns_mode]
-            blk["targets"] = "north_star: >=100x CPU, >=40% of the relevant roofline, indices bit-exact, outputs within 1e-3"
-            line["north_star"] = blk
-        print(json.dumps(line), flush=True)
-    if world > 1 or force_pg:
+            full["cpu_baseline"] = cpu_baseline()
+            full["gpu_over_cpu"] = full["value"] / full["cpu_baseline"]["value"]
+        full["detail_file"] = "bench_detail.json"
+        for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+            if os.path.isdir(os.path.dirname(path)):
+                try:
+                    with open(path, "w") as fh:
+                        json.dump(full, fh, indent=1)
+                except OSError:
+                    pass
+        line = compact_line(full)
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text) > LINE_LIMIT:                  # never again an unparsable round: drop the optional blocks, keep the contract
+            for k in ("configs", "modes", "grad_exchange"):
+                line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+        print(text, flush=True)
+    if multi:
         dist.destroy_process_group()
 
 

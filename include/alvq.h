@@ -170,14 +170,27 @@ int alvq_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_av
 
 /* Graph-replayable form: the step-dependent scalars come from device memory,
  * scalars = {lr / (1 - beta1^step), sqrt(1 - beta2^step), grad_scale}. */
+/* skip (nullable, here and in alvq_adam_pack_batch / alvq_adam_segments_f32): a device float, the SKIP SLOT of the flat
+ * gradient buffer.  Non-zero = this step saturated an fp16-range format on some rank (alvq_range_flag_to_slot wrote it
+ * before the step's all-reduce, which sums it over the ranks): the launch leaves parameters, moments and packed images
+ * bit for bit as they were -- the dynamic-loss-scaling "skip" pattern, decided on the device, no host sync. */
 int alvq_adam_dev_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                      const float* scalars, float beta1, float beta2, float eps, void* stream);
+                      const float* scalars, float beta1, float beta2, float eps, const float* skip, void* stream);
 
-/* Device-side step counter for the form above: scalars is FOUR floats, {.., .., .., step} (step starts at 0).  Each
- * call does step += 1 and rewrites the first three for that step, in stream order -- no host staging buffer, so a
- * host that queues steps ahead of the device cannot overwrite a step's scalars before its Adam launch reads them
- * (hyper-parameters and powers in double, as torch.optim.Adam computes them; exact step count up to 2^24). */
-int alvq_adam_advance_f32(float* scalars, double lr, double beta1, double beta2, double grad_scale, void* stream);
+/* Device-side step counter for the form above: scalars is EIGHT floats, {.., .., .., step, skipped, -, -, -} (both counters
+ * start at 0).  Each call does step += 1 and rewrites the first three for that step, in stream order -- no host staging
+ * buffer, so a host that queues steps ahead of the device cannot overwrite a step's scalars before its Adam launch reads
+ * them (hyper-parameters and powers in double, as torch.optim.Adam computes them; exact step count up to 2^24).
+ * prev_skip (nullable): the skip slot, still holding the PREVIOUS step's verdict (the flat gradient buffer is zeroed inside
+ * the step): if non-zero that step was not applied -- step stays, skipped += 1 (a GradScaler-skipped step does not advance
+ * torch.optim.Adam's step count either).  With prev_skip the call also folds the range flag's bits into its sticky word, so
+ * the step about to run sees only its own. */
+int alvq_adam_advance_f32(float* scalars, double lr, double beta1, double beta2, double grad_scale,
+                          const float* prev_skip, void* stream);
+
+/* *slot = 1.0f if the fp16-range formats' flag holds any bit raised since the step's guarded alvq_adam_advance_f32, else
+ * 0.0f.  The last launch of a step's backward; slot is element 0 of the flat gradient buffer. */
+int alvq_range_flag_to_slot(float* slot, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * STFT power spectrogram (scripts/genereate_dataset.py:90-91,37,39,47-49; torchaudio Spectrogram semantics:
@@ -247,12 +260,12 @@ typedef struct alvq_adam_pack_desc {
   int32_t dim0, dim1, KW;
 } alvq_adam_pack_desc;
 int alvq_adam_pack_batch(const alvq_adam_pack_desc* descs, int n, int planes, const float* scalars,
-                         float beta1, float beta2, float eps, void* stream);
+                         float beta1, float beta2, float eps, const float* skip, void* stream);
 /* alvq_adam_dev_f32 over the nseg element ranges [lo[i], hi[i]) of flat buffers, one launch (lo / hi: HOST arrays): the
  * parameters alvq_adam_pack_batch does not own (biases, the codebook). */
 int alvq_adam_segments_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                            const int64_t* lo, const int64_t* hi, int nseg, const float* scalars,
-                           float beta1, float beta2, float eps, void* stream);
+                           float beta1, float beta2, float eps, const float* skip, void* stream);
 
 /* (B,C,L) fp32 -> NLC-padded bf16 (the boundary conversion for x, quantized and incoming gradients). */
 int alvq_ncl_to_nlc_bf16(const float* x, void* y, int B, int C, int L, void* stream);

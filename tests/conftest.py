@@ -31,6 +31,16 @@ os.environ.setdefault("ALVQ_WIDE_MIN_TILES", "1")
 os.environ.setdefault("ALVQ_DTYPE", "f32")
 
 
+# Round 4 retired f16mx / bf16x3 / f16mx_hd as user-selectable modes (their forwards live on inside the _hb modes), but their
+# kernels are still product code the _hb modes run, and the kernel-level tests keep driving them through the internal engines:
+# inside the test session ``set_compute_dtype`` admits them.  tests/test_host_cpu.py checks the user-facing refusal in a
+# subprocess that does not load this file.
+from acoustic_locating_vq_vae import _ops as _ops_for_tests  # noqa: E402
+
+_set_dtype = _ops_for_tests.set_compute_dtype
+_ops_for_tests.set_compute_dtype = lambda name, internal=True: _set_dtype(name, internal)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -122,12 +122,15 @@ def test_flat_buffers_views_and_shard():
     b = torch.nn.Parameter(torch.randn(7))
     frozen = torch.nn.Parameter(torch.randn(2), requires_grad=False)
     fb = FlatBuffers([a, b, a, frozen])
-    assert len(fb.params) == 2 and fb.numel == 22 and fb.flat.numel() == 128
-    assert a.data_ptr() == fb.flat.data_ptr() and b.data_ptr() == fb.flat.data_ptr() + 64 * 4
+    # a 64-float header first (element 0 of the gradient buffer = the step's skip slot), then 256-byte aligned slots
+    assert len(fb.params) == 2 and fb.numel == 22 and fb.flat.numel() == 192
+    assert a.data_ptr() == fb.flat.data_ptr() + 64 * 4 and b.data_ptr() == fb.flat.data_ptr() + 128 * 4
+    assert fb.skip_slot.data_ptr() == fb.grad.data_ptr() and fb.skip_slot.numel() == 1
     (a.sum() * 2 + b.sum()).backward()
-    assert float(fb.grad[:15].sum()) == 30.0 and float(fb.grad[64:71].sum()) == 7.0
+    assert float(fb.grad[64:79].sum()) == 30.0 and float(fb.grad[128:135].sum()) == 7.0 and float(fb.grad[:64].abs().sum()) == 0.0
     fb.zero_grad()
-    assert float(fb.grad.abs().sum()) == 0.0 and a.grad.data_ptr() == fb.grad.data_ptr()
+    assert float(fb.grad.abs().sum()) == 0.0 and a.grad.data_ptr() == fb.grad.data_ptr() + 64 * 4
+    assert fb.span([a]) == (0, 128) and fb.span([b]) == (128, 192)      # a prefix span carries the header along
     x = torch.arange(8).view(8, 1)
     assert shard_batch(x, 1, 4).view(-1).tolist() == [2, 3]
     with pytest.raises(ValueError):

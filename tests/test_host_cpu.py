@@ -158,7 +158,8 @@ def test_overlay_resolves_non_hot_path_modules_from_the_reference():
 
 
 def test_package_default_mode_is_the_parity_holding_fast_mode():
-    """A user who sets nothing (scripts/train_speech.py unchanged) gets f16mx_hb; ALVQ_DTYPE overrides; junk is refused."""
+    """A user who sets nothing (scripts/train_speech.py unchanged) gets x3mx_hb; ALVQ_DTYPE overrides; junk -- and the
+    engines retired to internal use in round 4 -- are refused."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -167,8 +168,15 @@ def test_package_default_mode_is_the_parity_holding_fast_mode():
     env = {k: v for k, v in os.environ.items() if k != "ALVQ_DTYPE"}
     env["PYTHONPATH"] = os.pathsep.join([pkg, os.path.join(pkg, "src")])
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.stdout.split() == ["f16mx_hb", "f16mx_hb"], out.stdout + out.stderr
+    assert out.stdout.split() == ["x3mx_hb", "x3mx_hb"], out.stdout + out.stderr
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, ALVQ_DTYPE="f32"), capture_output=True, text=True, timeout=300)
-    assert out.stdout.split() == ["f32", "f16mx_hb"], out.stdout + out.stderr
-    out = subprocess.run([sys.executable, "-c", code], env=dict(env, ALVQ_DTYPE="fp64"), capture_output=True, text=True, timeout=300)
-    assert out.returncode != 0 and "ALVQ_DTYPE" in out.stderr
+    assert out.stdout.split() == ["f32", "x3mx_hb"], out.stdout + out.stderr
+    for junk in ("fp64", "f16mx", "bf16x3", "f16mx_hd"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(env, ALVQ_DTYPE=junk), capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "ALVQ_DTYPE" in out.stderr
+    code = ("from acoustic_locating_vq_vae import _ops\n"
+            "assert _ops.MODES == ('x3mx_hb', 'f16mx_hb', 'bf16x3_hb', 'f32', 'bf16')\n"
+            "try:\n    _ops.set_compute_dtype('f16mx')\n    raise SystemExit(3)\nexcept ValueError:\n    pass\n"
+            "_ops.set_compute_dtype('f16mx', internal=True)\nprint(_ops.get_compute_dtype())")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.split() == ["f16mx"], out.stdout + out.stderr
