@@ -49,14 +49,15 @@ __device__ __forceinline__ void split_pack8(const float (&v)[8], u32x4& hi, u32x
 // like that one, for few VALU instructions per value: a row block's offset is formed once, the skip / mask operands of
 // the whole row block are requested before the first group is finished, nothing is computed for absent operands, gap
 // rows are zeroed by a select on the packed words inside a wave-uniform branch.
-__device__ __forceinline__ void wave_epilogue_x3(const ConvX3Args& ax, const f32x4 (&acc)[8][4], int m0, int r0, int li,
+template <int NNI>
+__device__ __forceinline__ void wave_epilogue_x3(const ConvX3Args& ax, const f32x4 (&acc)[8][NNI], int m0, int r0, int li,
                                                  int kq, int wm0, int wn0) {
   const ConvBArgs& a = ax.b;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   const int mb0 = m0 + wm0 + (kq & 1) * 16 + (kq >> 1) * 8;
   const long pl = ax.y_plane;
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int ni = 0; ni < NNI; ++ni) {
     const int row = r0 + wn0 + ni * 16 + li;
     int b, l;
     const bool ok = row_valid(row, Lp1, ndata, &b, &l);
@@ -167,18 +168,25 @@ constexpr int X3_XSTAGE = 2 * X3_XSLAB;           // X hi, X lo of one chunk
 constexpr int X3_LDS2 = 2 * X3_WSTAGE + 2 * X3_XSTAGE;   // 135168 B
 static_assert(64 * X3_CS * 4 <= X3_LDS2, "C slab must fit");
 
-template <int OUT, int KW>
+// NNI: 16-row fragments per wave.  4 = the 256 x 256 tile (a wave owns 128 channels x 64 rows); 2 (round 4) = a 128-channel
+// m-tile x 256 rows: every wave owns all 128 channels x 32 rows, waves 0-3 stage the 128 weight rows.  For layers of at most
+// 128 output channels -- the pre-VQ convolution's 256-wide tile spent half of its MFMAs (171 us of the default mode's step) on
+// padding channels -- and for problems with too few 256 x 256 tiles to cover the chip (the RIR config's 1024-channel layers:
+// 104 tiles on 256 CUs -> 208 workgroups of half the work).  Same K order per output: results are bit-identical.
+template <int OUT, int KW, int NNI = 4>
 __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
+  static_assert(NNI == 4 || NNI == 2, "4 or 2 row fragments per wave");
   constexpr int PAD = (KW - 1) / 2;
+  constexpr int MT = NNI == 4 ? X3_M : 128;
   const ConvBArgs& a = ax.b;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  const int wm0 = (wave >> 2) * 128, wn0 = (wave & 3) * 64;
+  const int wm0 = NNI == 4 ? (wave >> 2) * 128 : 0, wn0 = NNI == 4 ? (wave & 3) * 64 : wave * 32;
 
   const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
-  const int m0 = (tile % a.mtiles) * X3_M;
+  const int m0 = (tile % a.mtiles) * MT;
   const int r0 = (tile / a.mtiles) * X3_R;
   const int Cp = a.Cp;
 
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
   const char* const xb = (const char*)(a.x + ((long)r0 - PAD + wave * 32) * Cp);
   constexpr unsigned XBASE = 2 * X3_WSTAGE;
   auto issueW = [&](int t) {   // K-tile t -> weight stage t & 1: 32 rows of W hi and of W lo per wave
+    if (wave * 32 >= MT) return;       // 128-channel m-tile: waves 0-3 stage the weight rows
     const int chunk = t / KW, tap = t - chunk * KW;
     const unsigned dst = lds0 + (t & 1) * X3_WSTAGE + wave * 2048;
     const char* ws = wb + tap * tap_w + chunk * (X3_K * 2);
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
   }
   const unsigned char* const abase = lds + wm0 * 64 + loffA;
   const unsigned char* const bbase = lds + XBASE + wn0 * 64;
-  bf16x8_t fa0[8], fa1[8], fb0[4], fb1[4];
+  bf16x8_t fa0[8], fa1[8], fb0[NNI], fb1[NNI];
 #define X3_RDA(DST, HALF, WS, PLANE)                                                               \
   {                                                                                                \
     const unsigned char* pa_ = abase + (WS) * X3_WSTAGE + (PLANE) * X3_SLAB;                       \
@@ -235,17 +244,17 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
 #define X3_RDB(DST, XS, TAP, PLANE)                                                                \
   {                                                                                                \
     const unsigned char* pb_ = bbase + (XS) * X3_XSTAGE + (PLANE) * X3_XSLAB + loffB[TAP];         \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) DST[ni] = *(const bf16x8_t*)(pb_ + ni * 1024); \
+    _Pragma("unroll") for (int ni = 0; ni < NNI; ++ni) DST[ni] = *(const bf16x8_t*)(pb_ + ni * 1024); \
   }
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NNI];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NNI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define X3_MM(A, B, HALF)                                                                          \
   _Pragma("unroll") for (int mi = (HALF) * 4; mi < (HALF) * 4 + 4; ++mi)                           \
-  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                 \
+  _Pragma("unroll") for (int ni = 0; ni < NNI; ++ni)                                               \
       asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(A[mi]), "v"(B[ni]));
 #define X3_SB __builtin_amdgcn_sched_barrier(0);
 
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
   // states by hand before the epilogue touches the accumulators
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
-  if (OUT == 0) {   // bf16 hi + lo planes, straight from the accumulators
+  if constexpr (OUT == 0) {   // bf16 hi + lo planes, straight from the accumulators
     wave_epilogue_x3(ax, acc, m0, r0, li, kq, wm0, wn0);
     return;
   }
@@ -318,12 +327,12 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
   float* Cs = (float*)lds;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
   for (int slab = 0; slab < 4; ++slab) {
-    if ((wave & 3) == slab) {
+    if ((wn0 >> 6) == slab) {          // the waves that own rows of this 64-row slab (four of them; two in the narrow tile)
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int rl = ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
+        for (int ni = 0; ni < NNI; ++ni) {
+          const int rl = (wn0 & 63) + ni * 16 + li, ml = wm0 + mi * 16 + kq * 4;
           *(f32x4*)(Cs + rl * X3_CS + ml) = acc[mi][ni];
         }
     }
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
       const int rl = tid & 63, row = r0 + slab * 64 + rl;
       int b, l;
       if (row_valid(row, Lp1, ndata, &b, &l)) {
-        for (int ml = tid >> 6; ml < X3_M; ml += 8) {
+        for (int ml = tid >> 6; ml < MT; ml += 8) {
           const int m = m0 + ml;
           if (m >= a.M) break;
           a.y_ncl[((long)b * a.M + m) * a.L + l] = Cs[rl * X3_CS + ml] + (a.bias ? a.bias[m] : 0.f);
@@ -751,9 +760,29 @@ extern "C" int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bi
     (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
   }
+  // fp32-NCL output of at most 128 channels (the pre-VQ convolution): 128-channel m-tile, no MFMA spent on padding channels
+  // (option "fx_narrow" = 0 switches it off here as in the f16mx kernel); results are bit-identical to the 256-wide tile's
+  // 128-channel m-tile: outputs of at most 128 channels (no MFMA spent on padding channels), and problems whose 256 x 256
+  // tiles would leave CUs idle (option "fx_narrow" = 0 switches it off here as in the f16mx kernel; "fx_rows" = 256 forces
+  // the wide tile for the second case); results are bit-identical to the 256-wide tile's
+  const int forced = (int)option(OPT_FX_ROWS);
+  const bool narrow = option(OPT_FX_NARROW) != 0 && (M <= 128 || (forced != 256 && a.b.rtiles * a.b.mtiles < 192) || forced == 128);
+  if (narrow) a.b.mtiles = pad_to(M, 128) / 128;
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
-  if (y) {
+  if (narrow) {
+    if (y) {
+      if (KW == 3) hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 3, 2>), grid, block, X3_LDS2, s, a);
+      else hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 1, 2>), grid, block, X3_LDS2, s, a);
+    } else {
+      if (KW == 3) hipLaunchKernelGGL((conv1d_bf16x3_kernel<1, 3, 2>), grid, block, X3_LDS2, s, a);
+      else hipLaunchKernelGGL((conv1d_bf16x3_kernel<1, 1, 2>), grid, block, X3_LDS2, s, a);
+    }
+  } else if (y) {
     if (KW == 3) hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 3>), grid, block, X3_LDS2, s, a);
     else hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 1>), grid, block, X3_LDS2, s, a);
   } else {

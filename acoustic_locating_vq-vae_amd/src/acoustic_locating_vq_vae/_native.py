@@ -61,6 +61,8 @@ _SIGNATURES = {
     "alvq_stft_complex_f64": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_fir_same_f64": (_i32, [_c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _c_void_p]),
     "alvq_spec_rir_wiener_f64": (_i32, [_c_void_p] * 7 + [_i32, _i32, _i32, _c_void_p]),
+    "alvq_rows_to_nlc": (_i32, [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p]),
+    "alvq_rows_to_nlc_max_std_rows": (_i32, []),
     "alvq_nlc_rows": (_i64, [_i32, _i32]),
     "alvq_nlc_channels": (_i32, [_i32]),
     "alvq_nlc_guard_rows": (_i32, []),
@@ -788,6 +790,24 @@ def ncl_to_nlc(x, planes=1, fmt=None, gscale=None):
         _check(lib().alvq_ncl_to_nlc_bf16x3(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16x3")
     else:
         _check(lib().alvq_ncl_to_nlc_bf16(_ptr(x, name="x"), out.ptr, B, C, L, _stream()), "alvq_ncl_to_nlc_bf16")
+    return out
+
+
+def rows_to_nlc_supported(fmt, L, standardise=False):
+    return fmt in ("bf16", "bf16x3", "f16mx") and (not standardise or 2 <= L <= lib().alvq_rows_to_nlc_max_std_rows())
+
+
+def rows_to_nlc(x_blc, planes=1, fmt=None, standardise=False, take_abs=False):
+    """(B, L, C) fp32 contiguous -- the model input (B, C, L) seen through ``permute(0, 2, 1)`` -- straight into the NLC
+    layout (channels are already contiguous: no transposition either way), optionally standardised over L per (b, c) in the
+    same pass (train_rir.py:43-44; bit-identical to standardise -> transpose -> ncl_to_nlc)."""
+    B, L, C = x_blc.shape
+    out = NLC(B, L, C, x_blc.device, planes, fmt)
+    if not rows_to_nlc_supported(out.fmt, L, standardise):
+        raise RuntimeError("rows_to_nlc: format %s / L = %d not supported" % (out.fmt, L))
+    code = {"bf16": 1, "bf16x3": 2, "f16mx": 3}[out.fmt]
+    _check(lib().alvq_rows_to_nlc(_ptr(x_blc, name="x"), out.ptr, B, C, L, code, int(bool(standardise)), int(bool(take_abs)), _stream()),
+           "alvq_rows_to_nlc")
     return out
 
 

@@ -378,6 +378,8 @@ def _wgrad(eng, dy, x, kw, layout, w, b=None, dw_prev=None):
 
 def dense(x):
     """Materialise a strided input as dense (B,C,L) fp32 on the GPU (train_rir.py:45 hands over a permuted view)."""
+    if isinstance(x, StandardisedT):
+        return x.materialise()
     if x.dtype != torch.float32:
         x = x.float()
     if x.is_contiguous():
@@ -385,6 +387,37 @@ def dense(x):
     if x.dim() == 3 and x.permute(0, 2, 1).is_contiguous():
         return N.transpose12(x.permute(0, 2, 1))
     return x.contiguous()
+
+
+class StandardisedT:
+    """The tensor ``standardise(raw).permute(0, 2, 1)`` of train_rir.py:42-45 -- raw (B, F, T) fp32 contiguous on the GPU,
+    standardised over dim 1, seen as (B, T, F) -- NOT materialised: the Trainer hands it to the model, the first engine to
+    ``enter`` it converts raw straight into its compute layout with the standardisation fused into that pass
+    (``N.rows_to_nlc``), the fp32 engine (and any format the fused kernel does not serve) materialises it."""
+
+    def __init__(self, raw):
+        self.raw = raw
+        b, f, t = raw.shape
+        self.shape = torch.Size((b, t, f))
+        self.device, self.is_cuda, self.dtype, self.requires_grad = raw.device, raw.is_cuda, raw.dtype, False
+
+    def dim(self):
+        return 3
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def materialise(self):
+        return N.transpose12(N.standardise(self.raw))
+
+
+def _as_blc(x):
+    """x (B, C, L) that is the ``permute(0, 2, 1)`` view of a contiguous fp32 (B, L, C) tensor -> that tensor, else None."""
+    if torch.is_tensor(x) and x.dim() == 3 and x.dtype == torch.float32 and not x.is_contiguous():
+        xt = x.permute(0, 2, 1)
+        if xt.is_contiguous():
+            return xt
+    return None
 
 
 def _need_gpu(x, who):
@@ -444,9 +477,27 @@ class _BF16Engine:
             return N.pack_weight(w.detach(), layout, self.wplanes)
         return _cached_pack(w, layout, self.wplanes)
 
+    def _enter_rows(self, x, planes, fmt):
+        """The input boundary without a transposition: a permuted view of a contiguous tensor (train_rir.py:45) or the
+        Trainer's not-yet-standardised batch has its channel axis contiguous already -- one pass, straight into the layout."""
+        if os.environ.get("ALVQ_ROWS_BOUNDARY", "1") == "0":
+            return None
+        if isinstance(x, StandardisedT):
+            if N.rows_to_nlc_supported(fmt, x.raw.shape[1], True):
+                return N.rows_to_nlc(x.raw, planes, fmt, standardise=True)
+            return None
+        blc = _as_blc(x)
+        if blc is not None and blc.is_cuda and N.rows_to_nlc_supported(fmt, blc.shape[1]):
+            return N.rows_to_nlc(blc, planes, fmt)
+        return None
+
     def enter(self, x, grad=False):
         """fp32 (B,C,L) -> the engine's layout.  ``grad``: x is a gradient entering a backward chain (only the f16mx
         engine cares: it picks the chain's loss scale from x)."""
+        if not grad:
+            hit = self._enter_rows(x, self.planes, self.fmt)
+            if hit is not None:
+                return hit
         return N.ncl_to_nlc(dense(x), self.planes)
 
     def leave(self, a):
@@ -490,6 +541,10 @@ class _F16MXEngine(_BF16Engine):
     fmt = "f16mx"
 
     def enter(self, x, grad=False):
+        if not grad:
+            hit = self._enter_rows(x, 2, "f16mx")
+            if hit is not None:
+                return hit
         x = dense(x)
         return N.ncl_to_nlc(x, 2, "f16mx", N.grad_scale(x) if grad else None)
 
@@ -508,6 +563,10 @@ class _F16MXHBEngine(_F16MXEngine):
     name = "f16mx_hb"
 
     def enter(self, x, grad=False):
+        if not grad:
+            hit = self._enter_rows(x, 2, "f16mx")
+            if hit is not None:
+                return hit
         x = dense(x)
         if grad:
             return N.ncl_to_nlc(x, 1, "f16", N.grad_scale(x))
@@ -522,6 +581,10 @@ class _BF16x3HBEngine(_BF16x3Engine):
     name = "bf16x3_hb"
 
     def enter(self, x, grad=False):
+        if not grad:
+            hit = self._enter_rows(x, 2, "bf16x3")
+            if hit is not None:
+                return hit
         return N.ncl_to_nlc(dense(x), 1 if grad else 2)
 
 

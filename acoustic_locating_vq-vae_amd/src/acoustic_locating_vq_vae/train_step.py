@@ -309,7 +309,9 @@ class Trainer:
             x = N.standardise(_ops.dense(raw), take_abs=True)
             return x, x
         if self.kind == "rir":
-            x = N.transpose12(N.standardise(_ops.dense(raw)))                        # (B, T, F): frames are channels
+            # (B, T, F): frames are channels -- standardise(raw).permute(0, 2, 1) (train_rir.py:42-45), left un-materialised: the
+            # encoder's first launch converts raw into its compute layout with the standardisation fused in (csrc/boundary.hip)
+            x = _ops.StandardisedT(_ops.dense(raw))
             w = wiener.float()
             tgt = N.standardise(w.unsqueeze(2).contiguous()).view(w.shape[0], 1, w.shape[1])
             return x, tgt
@@ -318,7 +320,7 @@ class Trainer:
 
     def forward_loss(self, x, target):
         if self.kind == "echoed":
-            recon, sp_perp, _ = self.model(x, N.transpose12(x))
+            recon, sp_perp, _ = self.model(x, x.permute(0, 2, 1))     # the view train_echoed_speech.py:66 passes; never materialised
             recon_error = _ops.MSEFn.apply(recon, target)
             return recon_error, recon_error, sp_perp
         vq_loss, recon, perplexity = self.model(x)
@@ -525,7 +527,7 @@ class Trainer:
         # of earlier collectives (hipEventQuery); under the default "global" mode such a call from another thread during
         # the capture is an error that invalidates it (seen as an intermittent hipErrorStreamCaptureInvalidated in
         # tests/test_rccl_gpu.py: about one capture in ten).  No collective is ever recorded into these graphs.
-        mode = os.environ.get("ALVQ_CAPTURE_MODE", "thread_local")
+        mode = self._capture_mode = os.environ.get("ALVQ_CAPTURE_MODE", "thread_local")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode=mode):
             self._static_out = self._body(self._static_raw, self._static_wiener)

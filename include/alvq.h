@@ -267,6 +267,16 @@ int alvq_adam_segments_f32(float* param, const float* grad, float* exp_avg, floa
                            const int64_t* lo, const int64_t* hi, int nseg, const float* scalars,
                            float beta1, float beta2, float eps, const float* skip, void* stream);
 
+/* Input boundary for a source whose CHANNEL axis is already contiguous (round 4; SURVEY 8(b) "element strides of x"):
+ * x is (B, L, C) fp32 contiguous -- i.e. the model input (B, C, L) handed over as `t.permute(0, 2, 1)` of a contiguous t,
+ * which is what scripts/train_rir.py:45 and scripts/train_echoed_speech.py:66 do -- and y the NLC-padded activation in format
+ * fmt (1 bf16, 2 bf16x3 hi + lo planes, 3 f16mx H + Q planes): y[row(b,l)][c] = x[b][l][c], no transposition in either
+ * direction.  standardise != 0 fuses train_rir.py:43-44 into the same pass: per (b, c) the mean and the UNBIASED std over l,
+ * (v - mean) / (std + 1e-8), in alvq_standardise_f32's arithmetic and summation order (bit-identical to standardise ->
+ * transpose -> convert); requires 2 <= L <= alvq_rows_to_nlc_max_std_rows().  take_abs applies |.| first. */
+int alvq_rows_to_nlc(const float* x, void* y, int B, int C, int L, int fmt, int standardise, int take_abs, void* stream);
+int alvq_rows_to_nlc_max_std_rows(void);
+
 /* (B,C,L) fp32 -> NLC-padded bf16 (the boundary conversion for x, quantized and incoming gradients). */
 int alvq_ncl_to_nlc_bf16(const float* x, void* y, int B, int C, int L, void* stream);
 

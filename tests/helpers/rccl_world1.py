@@ -16,7 +16,7 @@ import torch.distributed as dist  # noqa: E402
 
 
 def main():
-    mode = sys.argv[1] if len(sys.argv) > 1 else "f16mx"
+    mode = sys.argv[1] if len(sys.argv) > 1 else "x3mx_hb"
     steps = 3
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

@@ -1,12 +1,18 @@
-"""Every compute mode at the DEFAULT configs (speech / RIR / echoed ctor sizes) against the goldens made by the real
-reference (tests/golden/g3_*.npz).  The f32 mode's strict version lives in tests/test_modules_gpu.py; here the
-throughput mode (bf16) is held to measured floors and ceilings and the split parity modes (f16mx = bench.py's headline,
-bf16x3) to the north star's bar itself; every number is printed, and no assertion is conditional on another one passing.
+"""Every user-selectable compute mode at the DEFAULT configs (speech / RIR / echoed ctor sizes) against the goldens made by
+the real reference (tests/golden/g3_*.npz).  The f32 mode's strict version lives in tests/test_modules_gpu.py; here the
+throughput mode (bf16) is held to measured floors and ceilings and the parity modes to the north star's bar itself; every
+number is printed, and no assertion is conditional on another one passing.
 
-Measured on MI355X (B=2 goldens): bf16x3  z 6e-6, recon 7e-6, 0 code mismatches, grads <= 7e-3;
-                                  f16mx   z 1.3e-5 - 1.8e-5, recon 2.2e-5, 0 code mismatches, grads <= 7e-3;
-                                  bf16    z 3-4e-3, 99.0-99.1 % of codes agree (every flip a reference near-tie with
-                                          relative top-2 gap < 1e-3), recon rel-L2 0.05-0.11 (flipped codes), losses 1e-4."""
+Round 4: the DEFAULT mode x3mx_hb (bf16x3 forward for everything the codebook indices depend on, f16mx decoder forward,
+16-bit backward) must return EVERY index of EVERY golden -- == 0, no allowance -- including the RIR golden's 1.8e-6
+near-tie that the f16mx family flips; the allowance survives, named, for f16mx_hb only.  The retired engines f16mx / bf16x3
+(their forwards are the _hb modes' bit for bit: tests/test_f16mx_hb_gpu.py, tests/test_bf16x3_hb_gpu.py) left the golden matrices.
+
+Measured on MI355X (B=2 goldens): x3mx_hb   z 6.4e-6, recon 2.2e-5, 0 code mismatches, grads max-norm 4e-2 (rel-L2 median 1.6e-3);
+                                  bf16x3_hb z 6e-6, recon 7e-6, 0 code mismatches;
+                                  f16mx_hb  z 1.3e-5 - 1.8e-5, recon 2.2e-5, 0 code mismatches, grads <= 7e-3 rel-L2;
+                                  bf16      z 3-4e-3, 99.0-99.1 % of codes agree (every flip a reference near-tie with
+                                            relative top-2 gap < 1e-3), recon rel-L2 0.05-0.11 (flipped codes), losses 1e-4."""
 import json
 
 import pytest
@@ -40,7 +46,7 @@ def test_bf16_default_configs_against_reference_golden(mode, tag, golden_dir):
 
 
 @pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3_hb", "f16mx", "f16mx_hb"], indirect=True)
+@pytest.mark.parametrize("mode", ["x3mx_hb", "bf16x3_hb", "f16mx_hb"], indirect=True)
 def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_dir):
     """The north star's bar, unconditionally: codebook indices BIT-EXACT (0 of 1000 / 402 differ -- the goldens' smallest
     relative top-2 gap is 3e-5, so there is no near-tie to excuse), outputs within 1e-3 (measured 2e-5) on 4096-element
@@ -68,7 +74,7 @@ def test_split_modes_default_configs_against_reference_golden(mode, tag, golden_
         assert r["encoders_grad_free"]
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_hb", "f16mx", "f16mx_hb", "f16mx_hd", "bf16"], indirect=True)
+@pytest.mark.parametrize("mode", ["f32", "x3mx_hb", "bf16x3_hb", "f16mx_hb", "bf16"], indirect=True)
 def test_speech_config_at_a_training_batch_against_reference_golden(mode, golden_dir):
     """G3-speech at B = 16 (round 3; made by the real reference): 8 000 codebook rows, 22 of them with a relative top-2
     distance gap below 1e-4 and the smallest at 6.9e-6 -- every parity mode must still return ALL 8 000 indices of the
@@ -86,19 +92,18 @@ def test_speech_config_at_a_training_batch_against_reference_golden(mode, golden
     assert r["idx_mismatches"] == 0, r
     assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-5 and r["vq_loss_rel"] < 1e-5 and r["perplexity_rel"] < 1e-5, r
     assert r["recon_error_rel"] < 1e-5, r
-    if mode == "f16mx_hd":
-        assert r["recon_rel_max"] < 1e-3 and r["grad_rel_max"] < 0.1 and r["grad_rel_l2_median"] < 1e-2, r
-        return
     assert r["recon_rel_max"] < 1e-4 and r["recon_sum_rel"] < 1e-5, r
     if mode == "f32":
         assert r["grad_rel_max"] < 3e-3 and r["grad_rel_l2_max"] < 1e-3 and r["grad_sum_rel_max"] < 1e-4, r
     else:
-        # bf16x3_hb: the backward's bf16 operands (2^-9) set a floor of ~2e-3 under every tensor's rel-L2
-        assert r["grad_rel_max"] < 5e-2 and r["grad_rel_l2_max"] < 3e-2 and r["grad_rel_l2_median"] < (5e-3 if mode == "bf16x3_hb" else 2e-3), r
-        assert r["grad_sum_rel_max"] < (3e-3 if mode == "bf16x3_hb" else 5e-4) and r["encoder_grad_rel_max"] < 2e-2, r
+        # bf16 operands in a backward (bf16x3_hb everywhere, x3mx_hb on the encoder side: 2^-9) set a floor of ~2e-3 under
+        # those tensors' rel-L2
+        b16bwd = mode in ("bf16x3_hb", "x3mx_hb")
+        assert r["grad_rel_max"] < 5e-2 and r["grad_rel_l2_max"] < 3e-2 and r["grad_rel_l2_median"] < (5e-3 if b16bwd else 2e-3), r
+        assert r["grad_sum_rel_max"] < (3e-3 if b16bwd else 5e-4) and r["encoder_grad_rel_max"] < 2e-2, r
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_hb", "f16mx", "f16mx_hb", "f16mx_hd", "bf16"], indirect=True)
+@pytest.mark.parametrize("mode", ["f32", "x3mx_hb", "bf16x3_hb", "f16mx_hb", "bf16"], indirect=True)
 def test_the_bench_workload_against_reference_golden(mode, golden_dir):
     """G3-speech at B = 64: BASELINE configs[1] itself -- the batch bench.py times -- run by the real reference on the CPU
     (tests/golden/g3_speech_b64.npz: 32 000 codebook rows, 92 of them with a relative top-2 gap below 1e-4, the smallest
@@ -117,38 +122,38 @@ def test_the_bench_workload_against_reference_golden(mode, golden_dir):
     assert r["idx_mismatches"] == 0, r
     assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-5 and r["vq_loss_rel"] < 1e-5 and r["perplexity_rel"] < 1e-5, r
     assert r["recon_error_rel"] < 1e-5, r
-    if mode == "f16mx_hd":
-        assert r["recon_rel_max"] < 1e-3 and r["grad_rel_max"] < 0.1 and r["grad_rel_l2_median"] < 1e-2, r
-        return
     assert r["recon_rel_max"] < 1e-4 and r["recon_sum_rel"] < 1e-5, r
     if mode == "f32":
         assert r["grad_rel_max"] < 5e-3 and r["grad_rel_l2_max"] < 1e-3 and r["grad_sum_rel_max"] < 1e-4, r
     else:
-        assert r["grad_rel_max"] < 2e-2 and r["grad_rel_l2_max"] < 1.5e-2 and r["grad_rel_l2_median"] < (5e-3 if mode == "bf16x3_hb" else 1e-3), r
-        assert r["grad_sum_rel_max"] < (3e-3 if mode == "bf16x3_hb" else 5e-4) and r["encoder_grad_rel_max"] < 1e-2, r
+        b16bwd = mode in ("bf16x3_hb", "x3mx_hb")
+        assert r["grad_rel_max"] < 2e-2 and r["grad_rel_l2_max"] < 1.5e-2 and r["grad_rel_l2_median"] < (5e-3 if b16bwd else 1e-3), r
+        assert r["grad_sum_rel_max"] < (3e-3 if b16bwd else 5e-4) and r["encoder_grad_rel_max"] < 1e-2, r
+
+
+F16MX_FAMILY_NEAR_TIE_ALLOWANCE = 1      # f16mx_hb ONLY: the RIR golden's 1.8e-6 reference near-tie (see the docstring below)
 
 
 @pytest.mark.parametrize("tag", ["rir_b32", "echoed_b32"])
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_hb", "f16mx", "f16mx_hb", "bf16"], indirect=True)
+@pytest.mark.parametrize("mode", ["f32", "x3mx_hb", "bf16x3_hb", "f16mx_hb", "bf16"], indirect=True)
 def test_rir_and_echoed_at_their_per_gpu_batch_against_reference_golden(mode, tag, golden_dir):
     """BASELINE configs[2] / [4] at their per-GPU share (B = 32), run by the real reference.  The RIR golden holds 6 432
     codebook rows of which TWO are reference near-ties of 1.3e-6 and 1.8e-6 relative (11 and 15 fp32 ulps between the two
-    nearest codes).  f32 and bf16x3 return all 6 432 reference indices.  The f16mx family (z within 1.5e-5) returns 6 431: it
-    flips the 1.8e-6 row -- the ONE flipped index in the 47 834 rows of all the goldens (speech B = 2 / 16 / 64, RIR B = 2 / 32),
-    whose other 130 rows with a gap below 1e-4 (down to 4.2e-6) it resolves.  A flipped code is a different decoder input at
-    one position: the reconstruction differs locally (rel-max 6e-2 over ~11 positions, rel-L2 7e-3) and so does the echoed
-    model's, which embeds this RIR encoder.  That is the resolution limit of 3-bit-mantissa cross terms, stated here and
-    in DESIGN section 3 instead of choosing goldens that avoid it; strict users select bf16x3 or f32.
-    The bars below are this golden's measured behaviour, unconditional."""
+    nearest codes).  The DEFAULT mode x3mx_hb -- like f32 and bf16x3_hb -- must return ALL 6 432 reference indices, the
+    reconstruction inside 1e-4 and the echoed model's (which embeds this RIR encoder) likewise: == 0, no allowance.
+    f16mx_hb (z within 1.5e-5) returns 6 431: it flips the 1.8e-6 row -- the ONE flipped index in the 47 834 rows of all the
+    goldens -- and a flipped code is a different decoder input at one position (reconstruction rel-max 6e-2 over ~11
+    positions, rel-L2 7e-3; the echoed model inherits it).  That is the resolution limit of 3-bit-mantissa cross terms and
+    the reason f16mx_hb stopped being the default in round 4; its bars below are that golden's measured behaviour, named."""
     r = run(tag, golden_dir)
     print("g3-%s %s: %s" % (tag, mode, json.dumps(r)))
-    fx = mode.startswith("f16mx")
+    fx = mode == "f16mx_hb"
     if tag == "rir_b32":
         assert r["idx_total"] == 6432
         if mode == "bf16":
             assert r["idx_agree"] >= 0.985 and r["mismatch_gap_max"] < 5e-3 and r["z_rel_l2"] < 1.5e-2, r
         else:
-            assert r["idx_mismatches"] <= (1 if fx else 0) and r["mismatch_gap_max"] < 5e-6, r
+            assert r["idx_mismatches"] <= (F16MX_FAMILY_NEAR_TIE_ALLOWANCE if fx else 0) and r["mismatch_gap_max"] < 5e-6, r
             assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-5 and r["vq_loss_rel"] < 1e-5, r
     if mode == "bf16":
         assert r["recon_error_rel"] < 1e-2 and r["recon_rel_l2"] < 0.25 and r["grad_rel_l2_median"] < 0.3, r
@@ -162,26 +167,6 @@ def test_rir_and_echoed_at_their_per_gpu_batch_against_reference_golden(mode, ta
         assert r["grad_rel_max"] < (5e-3 if mode == "f32" else 3e-2) and r["grad_rel_l2_max"] < (3e-3 if mode == "f32" else 1.5e-2), r
     if tag == "echoed_b32":
         assert r["encoders_grad_free"]
-
-
-@pytest.mark.parametrize("tag", ["speech", "rir", "echoed"])
-@pytest.mark.parametrize("mode", ["f16mx_hd"], indirect=True)
-def test_half_decoder_mode_default_configs_against_reference_golden(mode, tag, golden_dir):
-    """f16mx_hd (opt-in): the encoder / quantiser side is f16mx_hb's bit for bit -- same index and z bars as above -- and the
-    decoder's forward runs on fp16 operands, so the reconstruction carries fp16's operand rounding through ~10 layers:
-    inside the north star's 1e-3 but with a margin of 1.5x, not 50x (measured rel-max 6.7e-4 speech).  That margin is why
-    the mode is not the default."""
-    r = run(tag, golden_dir)
-    print("g3-%s %s: %s" % (tag, mode, json.dumps(r)))
-    if tag != "echoed":
-        assert r["idx_mismatches"] == 0, r
-        assert r["z_rel_max"] < 1e-4 and r["z_sum_rel"] < 1e-5, r
-        assert r["vq_loss_rel"] < 1e-5 and r["perplexity_rel"] < 1e-5, r
-    assert r["recon_error_rel"] < 1e-5, r
-    assert r["recon_rel_max"] < 1e-3 and r["recon_rel_l2"] < 1e-3 and r["recon_sum_rel"] < 2e-4, r
-    # gradients: the decoder's fp16 forward noise (~3e-4) flips ~30x the ReLU gates the f16mx forward does, at B = 2 that is
-    # per-tensor rel-L2 up to 8e-2 (median 1e-3 speech, 1.3e-2 RIR, 2e-2 echoed) -- mixed-precision-training grade, bf16's is 0.1-0.6
-    assert r["grad_rel_max"] < 0.2 and r["grad_rel_l2_median"] < 5e-2 and r["grad_sum_rel_max"] < 2e-2, r
 
 
 @pytest.fixture

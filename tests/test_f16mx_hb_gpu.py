@@ -130,7 +130,7 @@ def test_deferred_batched_split_reduction_is_bitwise_the_immediate_one(mode, gra
     assert torch.isfinite(flats["1"]).all() and torch.equal(flats["1"], flats["0"])
 
 
-@pytest.mark.parametrize("mode", ["f16mx_hb", "bf16", "bf16x3", "f16mx"])
+@pytest.mark.parametrize("mode", ["x3mx_hb", "f16mx_hb", "bf16", "bf16x3", "f16mx"])
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
 def test_fused_adam_pack_is_bitwise_adam_then_pack(mode, graph, monkeypatch):
     """The optimiser launch that also emits the packed images of the conv weights (alvq_adam_pack_batch + one segmented

@@ -206,7 +206,7 @@ def test_adam_device_step_counter_matches_torch_without_host_syncs():
     grads = [torch.randn(n) for _ in range(6)]
     gdev = [dev(g) for g in grads]
     p, m, v = dev(p0.clone()), torch.zeros(n).cuda(), torch.zeros(n).cuda()
-    scalars = torch.zeros(4, device="cuda")
+    scalars = torch.zeros(N.ADAM_SCALARS, device="cuda")
     torch.cuda.synchronize()
     for g in gdev:                                   # no sync inside: every step's scalars come from the device
         N.adam_advance(scalars, 1e-3, 0.9, 0.999, 1.0)

@@ -328,7 +328,7 @@ def test_graph_replay_equals_eager_steps():
     assert float((finals[0][1] - finals[1][1]).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("mode", ["f32", "f16mx_hb"])
+@pytest.mark.parametrize("mode", ["f32", "x3mx_hb"])
 def test_ragged_batch_after_capture_runs_eagerly(mode):
     """The last batch of an epoch is smaller than the captured one: it must run (as eager launches) with exactly the result
     a Trainer without graphs gives, and the replays must carry on afterwards.  A one-sample batch is the nasty case: copy_

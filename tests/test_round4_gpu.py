@@ -1,0 +1,200 @@
+"""Round 4: the guards around the default mode.
+
+* a step whose values saturate an fp16-range format (or turn NaN) is SKIPPED on the device -- parameters, moments and packed
+  weights bit-identical to before it, the step count not advanced, a device counter incremented -- eager and from the
+  captured graphs; strict mode raises at the periodic check (round-3 verdict item 3: "a skipped step, not a late warning");
+* the deferred split reduction with MORE than four uses of a shared residual weight (two descriptors into one gradient
+  sink: round-3 advisor finding) is bit-identical to the immediate reductions;
+* the ragged last batch of a captured Trainer WITH jitter draws fresh columns and leaves np.random where an uncaptured run
+  leaves it (round-3 advisor finding);
+* the per-role default mode: its encoder side is bf16x3_hb's bit for bit, its decoder is f16mx_hb's arithmetic."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = (20, 48, 8, 2, 24, 0.25, 64)
+
+
+def _model(cfg=CFG, seed=0, use_jitter=True):
+    from acoustic_locating_vq_vae.vq_vae.convolutional_vq_vae import ConvolutionalVQVAE
+    torch.manual_seed(seed)
+    m = ConvolutionalVQVAE(*cfg, use_jitter=use_jitter).cuda().train()
+    with torch.no_grad():
+        m._vq._embedding.weight.normal_(0, 0.7)
+    return m
+
+
+@pytest.fixture
+def mode(request):
+    from acoustic_locating_vq_vae import _ops
+    _ops.set_compute_dtype(request.param)
+    yield request.param
+    _ops.set_compute_dtype("f32")
+
+
+def _raw(b, s):
+    return torch.randn(b, 20, 40, generator=torch.Generator().manual_seed(s)).cuda()
+
+
+@pytest.mark.parametrize("how", ["nan_input", "activation_beyond_65504"])
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+@pytest.mark.parametrize("mode", ["x3mx_hb", "f16mx_hb"], indirect=True)
+def test_saturated_step_is_skipped_on_the_device(mode, graph, how):
+    from acoustic_locating_vq_vae import _native as N
+    from acoustic_locating_vq_vae.train_step import Trainer
+    m = _model()
+    tr = Trainer(m, "speech", range_check_every=0)
+    np.random.seed(3)
+    if graph:
+        tr.capture(_raw(4, 0), warmup=2)
+    else:
+        for _ in range(2):
+            tr.step(_raw(4, 0))
+    N.f16mx_range_flag(reset=True)
+    tr.step(_raw(4, 1))
+    torch.cuda.synchronize()
+    applied0 = float(tr.opt.scalars[3])
+    bias = m._decoder._conv_1.bias
+    good_bias = bias.detach().clone()
+    if how == "nan_input":
+        bad = _raw(4, 2)
+        bad[1, 3, 5] = float("nan")
+    else:                                           # the decoder's first convolution produces values past fp16's range
+        bad = _raw(4, 2)
+        with torch.no_grad():
+            bias.fill_(1.0e5)
+    before = {k: t.clone() for k, t in (("w", tr.buffers.flat), ("m", tr.opt.exp_avg), ("v", tr.opt.exp_avg_sq))}
+    images = {k: img.clone() for k, (img, _) in tr.pack_pool._entries.items()}
+    tr.step(bad)                                    # step k: saturates
+    torch.cuda.synchronize()
+    assert float(tr.buffers.skip_slot) == 1.0
+    assert torch.equal(before["w"], tr.buffers.flat) and torch.equal(before["m"], tr.opt.exp_avg) and torch.equal(before["v"], tr.opt.exp_avg_sq)
+    for k, (img, _) in tr.pack_pool._entries.items():
+        assert torch.equal(images[k], img), k       # packed weight images untouched as well
+    if how != "nan_input":
+        with torch.no_grad():
+            bias.copy_(good_bias)
+    tr.step(_raw(4, 3))                             # clean steps proceed
+    tr.step(_raw(4, 4))
+    torch.cuda.synchronize()
+    assert float(tr.buffers.skip_slot) == 0.0
+    assert not torch.equal(before["w"], tr.buffers.flat) and bool(torch.isfinite(tr.buffers.flat).all())
+    assert float(tr.opt.scalars[3]) == applied0 + 2        # three more attempts, two applied: the skipped one does not count
+    assert tr.opt.skipped_steps(reset=False) == 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        flag = tr.check_range()
+    assert flag != 0 and tr.skipped_steps == 1 and any("SKIPPED" in str(x.message) for x in w)
+    assert tr.opt.skipped_steps() == 0 and tr.check_range() == 0          # read and cleared
+
+
+@pytest.mark.parametrize("mode", ["x3mx_hb"], indirect=True)
+def test_strict_range_mode_raises_when_steps_were_skipped(mode):
+    from acoustic_locating_vq_vae.train_step import Trainer
+    tr = Trainer(_model(), "speech", range_check_every=1, strict_range=True)
+    np.random.seed(3)
+    tr.step(_raw(4, 0))
+    bad = _raw(4, 1)
+    bad[0, 0, 0] = float("inf")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr.step(bad)
+        tr.step(_raw(4, 2))        # the flag is reported here (a warning: nothing is counted yet -- the NEXT advance counts)
+    with pytest.raises(FloatingPointError, match="SKIPPED"):
+        tr.step(_raw(4, 3))
+
+
+def test_unguarded_adam_applies_a_saturated_step(monkeypatch):
+    """ALVQ_SKIP_SATURATED=0 restores round 3's apply-and-warn behaviour -- and shows what the guard prevents: NaN parameters."""
+    from acoustic_locating_vq_vae import _ops
+    from acoustic_locating_vq_vae.train_step import Trainer
+    monkeypatch.setenv("ALVQ_SKIP_SATURATED", "0")
+    _ops.set_compute_dtype("x3mx_hb")
+    try:
+        tr = Trainer(_model(), "speech", range_check_every=0)
+        np.random.seed(3)
+        tr.step(_raw(4, 0))
+        bad = _raw(4, 1)
+        bad[0, 0, 0] = float("nan")
+        tr.step(bad)
+        torch.cuda.synchronize()
+        assert not tr.opt.guard and not bool(torch.isfinite(tr.buffers.flat).all())
+    finally:
+        _ops.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("mode", ["f16mx_hb", "bf16", "x3mx_hb"], indirect=True)
+def test_deferred_reduce_is_safe_beyond_four_shared_uses(mode, monkeypatch):
+    """R = 5 residual layers: the shared weights are used five times, outside the fused multi-segment launch (1 < R <= 4), so
+    five deferred descriptors name ONE gradient sink.  The batch launch sums descriptors in concurrent workgroups; the fix
+    flushes the pending batch when a destination repeats.  Bit for bit against ALVQ_DEFER_REDUCE=0, three steps, repeated."""
+    from acoustic_locating_vq_vae.train_step import Trainer
+    cfg = (20, 48, 8, 5, 24, 0.25, 64)
+    finals = []
+    for defer in ("0", "1", "1"):
+        monkeypatch.setenv("ALVQ_DEFER_REDUCE", defer)
+        tr = Trainer(_model(cfg, use_jitter=False), "speech", range_check_every=0)
+        for s in range(3):
+            tr.step(_raw(6, s))
+        torch.cuda.synchronize()
+        finals.append(tr.buffers.flat.clone())
+    assert torch.equal(finals[0], finals[1]) and torch.equal(finals[1], finals[2])
+
+
+@pytest.mark.parametrize("mode", ["f32", "x3mx_hb"], indirect=True)
+def test_ragged_batch_after_capture_draws_fresh_jitter(mode):
+    """train_speech.py's DataLoader has no drop_last and the model jitters: the ragged last batch of a captured Trainer must
+    draw its own jitter columns (the pinned buffers only change in refresh()) and leave np.random exactly where the same
+    sequence without graphs leaves it."""
+    from acoustic_locating_vq_vae.train_step import Trainer
+    seq = [_raw(4, 1), _raw(3, 2), _raw(4, 3), _raw(1, 4), _raw(4, 5)]
+    finals = []
+    for use_graph in (False, True):
+        tr = Trainer(_model(seed=7, use_jitter=True), "speech", range_check_every=0)
+        np.random.seed(11)
+        if use_graph:
+            tr.capture(_raw(4, 0), warmup=2)
+        else:
+            for _ in range(2):
+                tr.step(_raw(4, 0))
+        losses = [float(tr.step(r)[0]) for r in seq]
+        finals.append((losses, tr.buffers.flat.clone(), np.random.get_state()))
+    (l0, f0, s0), (l1, f1, s1) = finals
+    assert s0[2] == s1[2] and np.array_equal(s0[1], s1[1])                  # same number of draws consumed
+    assert np.allclose(l0, l1, rtol=1e-5), (l0, l1)
+    assert float((f0 - f1).abs().max()) < 1e-5
+
+
+def test_default_mode_is_bf16x3_encoder_plus_f16mx_decoder():
+    """x3mx_hb has no arithmetic of its own: z, VQ loss, perplexity and indices are bf16x3_hb's BIT FOR BIT (the encoder side
+    runs that engine); fed the same quantised latents its decoder is f16mx_hb's bit for bit; the encoder-side gradients
+    arrive through a bf16 chain, the decoder's through an fp16 chain under the loss scale."""
+    from acoustic_locating_vq_vae import _ops
+    m = _model(use_jitter=False)
+    x = _raw(4, 9)
+    out = {}
+    try:
+        for md in ("x3mx_hb", "bf16x3_hb", "f16mx_hb"):
+            _ops.set_compute_dtype(md)
+            m.zero_grad()
+            vq_loss, recon, perp = m(x)
+            (recon.square().mean() + vq_loss).backward()
+            _, q, _, idx = m.get_latent_indices(x)
+            out[md] = (vq_loss.detach().clone(), perp.detach().clone(), idx.clone(), recon.detach().clone(), q.detach().clone(),
+                       m._encoder._conv_1.weight.grad.clone(), m._decoder._conv_trans_3.weight.grad.clone())
+        _ops.set_compute_dtype("f16mx_hb")
+        dec_fx = m._decoder(out["x3mx_hb"][4]).detach()
+    finally:
+        _ops.set_compute_dtype("f32")
+    a, b = out["x3mx_hb"], out["bf16x3_hb"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
+    assert torch.equal(a[3], dec_fx)                                          # decoder = f16mx arithmetic on those latents
+    assert not torch.equal(a[3], b[3])                                        # ... and not bf16x3's
+    for md in ("bf16x3_hb", "f16mx_hb"):                                      # gradients: same function, 16-bit backward noise
+        for k in (5, 6):
+            rel = float((a[k] - out[md][k]).norm() / out[md][k].norm())
+            assert rel < 2e-2, (md, k, rel)

@@ -89,7 +89,7 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16x3", 2e-3), ("f16mx", 2e-3), ("f16mx_hb", 2e-3), ("bf16x3_hb", 4e-3)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("x3mx_hb", 8e-3), ("f16mx_hb", 2e-3), ("bf16x3_hb", 4e-3)])
 def test_speech_script_loop_tracks_the_cpu_reference_path(dtype, tol):
     from acoustic_locating_vq_vae import _ops
     cfg = (20, 48, 8, 2, 24, 0.25, 64)          # in, H, D, R, RH, beta, K
@@ -107,6 +107,8 @@ def test_speech_script_loop_tracks_the_cpu_reference_path(dtype, tol):
     finally:
         _ops.set_compute_dtype(prev)
     print(dtype, "got", got, "want", want)
+    # x3mx_hb: measured 4.0e-3 on the LAST step's loss -- one of the 99 rows changes its code after three updates (perplexity
+    # 32.65 against 32.39), which moves that step's losses by the weight of one row; the first three steps agree to 1e-6 / 5e-4
     for g, w in zip(got, want):
         for i, (a, b) in enumerate(zip(g, w)):
             # the perplexity of 99 rows over 64 codes moves by 2 % when ONE row changes its code: the modes with a reduced-
@@ -137,7 +139,7 @@ def test_rir_script_loop_with_permuted_input_tracks_the_cpu_reference_path():
         assert rel(sd[k], v.detach()) < 2e-3, k
 
 
-@pytest.mark.parametrize("dtype", ["f16mx", "bf16"])
+@pytest.mark.parametrize("dtype", ["x3mx_hb", "bf16"])
 def test_packed_weight_cache_follows_the_version_counter(dtype, monkeypatch):
     """Outside a Trainer the packed (weight, layout) images are cached per parameter VERSION: a training step packs each
     image once (not once per use / per autograd node), an unchanged model (evaluation) packs nothing, every in-place update

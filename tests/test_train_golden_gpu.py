@@ -18,8 +18,8 @@ pytestmark = pytest.mark.gpu
 from acoustic_locating_vq_vae import _ops  # noqa: E402
 from g3_cases import O, _build  # noqa: E402
 
-BARS = {"f32": (5e-4, 1e-2), "bf16x3": (3e-3, 2e-2), "bf16x3_hb": (3e-3, 2e-2), "f16mx": (3e-3, 2e-2), "f16mx_hb": (3e-3, 2e-2), "f16mx_hd": (5e-3, 3e-2),
-        "bf16": (2e-2, 5e-2)}
+# the user-selectable modes (round 4: f16mx / bf16x3 / f16mx_hd are internal engines; their forwards live on inside the _hb modes)
+BARS = {"f32": (5e-4, 1e-2), "x3mx_hb": (3e-3, 2e-2), "bf16x3_hb": (3e-3, 2e-2), "f16mx_hb": (3e-3, 2e-2), "bf16": (2e-2, 5e-2)}
 
 
 @pytest.mark.parametrize("mode", list(BARS))
@@ -50,7 +50,7 @@ def test_six_reference_train_steps_at_the_default_config(mode, golden_dir):
 
 
 # (loss after the first update, loss over all four steps, perplexity over all four steps)
-RIR_BARS = {"f32": (1.5e-3, 6e-3, 0.1), "bf16x3": (3e-3, 1e-2, 0.1), "bf16x3_hb": (3e-3, 1e-2, 0.1), "f16mx": (3e-3, 1e-2, 0.1), "f16mx_hb": (3e-3, 1e-2, 0.1),
+RIR_BARS = {"f32": (1.5e-3, 6e-3, 0.1), "x3mx_hb": (3e-3, 1e-2, 0.1), "bf16x3_hb": (3e-3, 1e-2, 0.1), "f16mx_hb": (3e-3, 1e-2, 0.1),
             "bf16": (0.15, 0.3, 0.3)}
 
 
@@ -85,7 +85,7 @@ def test_four_reference_train_steps_of_the_rir_loop(mode, golden_dir):
     assert dl[1] < RIR_BARS[mode][0] and dl.max() < RIR_BARS[mode][1] and dp.max() < RIR_BARS[mode][2]
 
 
-ECHOED_BARS = {"f32": (1e-4, 1e-5), "bf16x3": (1e-3, 1e-5), "bf16x3_hb": (1e-3, 1e-5), "f16mx": (1e-3, 1e-5), "f16mx_hb": (1e-3, 1e-5), "bf16": (2e-2, 2e-2)}
+ECHOED_BARS = {"f32": (1e-4, 1e-5), "x3mx_hb": (1e-3, 1e-5), "bf16x3_hb": (1e-3, 1e-5), "f16mx_hb": (1e-3, 1e-5), "bf16": (2e-2, 2e-2)}
 
 
 @pytest.mark.parametrize("mode", list(ECHOED_BARS))
