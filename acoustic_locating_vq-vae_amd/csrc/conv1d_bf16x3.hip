@@ -172,22 +172,25 @@ static_assert(64 * X3_CS * 4 <= X3_LDS2, "C slab must fit");
 // m-tile x 256 rows: every wave owns all 128 channels x 32 rows, waves 0-3 stage the 128 weight rows.  For layers of at most
 // 128 output channels -- the pre-VQ convolution's 256-wide tile spent half of its MFMAs (171 us of the default mode's step) on
 // padding channels -- and for problems with too few 256 x 256 tiles to cover the chip (the RIR config's 1024-channel layers:
-// 104 tiles on 256 CUs -> 208 workgroups of half the work).  Same K order per output: results are bit-identical.
+// 104 tiles on 256 CUs -> 208 workgroups of half the work).  1 = 128 channels x 128 rows (a wave owns 128 x 16; waves 0-3 stage
+// the activation rows as well): twice the workgroups again for the launches that still leave CUs idle (the speech pre-VQ
+// convolution: 126 -> 251 workgroups).  Same K order per output: results are bit-identical.
 template <int OUT, int KW, int NNI = 4>
 __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
-  static_assert(NNI == 4 || NNI == 2, "4 or 2 row fragments per wave");
+  static_assert(NNI == 4 || NNI == 2 || NNI == 1, "4, 2 or 1 row fragments per wave");
   constexpr int PAD = (KW - 1) / 2;
   constexpr int MT = NNI == 4 ? X3_M : 128;
+  constexpr int RT = NNI == 1 ? 128 : X3_R;
   const ConvBArgs& a = ax.b;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  const int wm0 = NNI == 4 ? (wave >> 2) * 128 : 0, wn0 = NNI == 4 ? (wave & 3) * 64 : wave * 32;
+  const int wm0 = NNI == 4 ? (wave >> 2) * 128 : 0, wn0 = NNI == 4 ? (wave & 3) * 64 : wave * 16 * NNI;
 
   const int tile = xcd_remap(blockIdx.x, a.mtiles * a.rtiles);
   const int m0 = (tile % a.mtiles) * MT;
-  const int r0 = (tile / a.mtiles) * X3_R;
+  const int r0 = (tile / a.mtiles) * RT;
   const int Cp = a.Cp;
 
   // ---- DMA: a piece is 16 rows x 64 B; lane i -> row i>>2, slot i&3 <- channel group (i&3) ^ h[(row>>2)&3]
@@ -217,11 +220,12 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
     dma(ws + wpl + row16, dst + X3_SLAB + 1024);
   };
   auto issueX = [&](int chunk, int plane) {   // one plane of a chunk's activation slab -> activation stage chunk & 1
+    if (wave * 32 >= RT) return;       // 128-row tile: waves 0-3 stage the activation rows
     const unsigned dst = lds0 + XBASE + (chunk & 1) * X3_XSTAGE + plane * X3_XSLAB + wave * 2048;
     const char* xs = xb + plane * xpl + chunk * (X3_K * 2);
     dma(xs, dst);
     dma(xs + row16, dst + 1024);
-    if (KW == 3 && wave == 7 && srow < 2) dma(xs + 2 * row16, dst + 2048);   // halo: slab rows 256, 257
+    if (KW == 3 && wave == RT / 32 - 1 && srow < 2) dma(xs + 2 * row16, dst + 2048);   // halo: slab rows RT, RT + 1
   };
 
   // ---- fragment reads (plane 0 = hi, 1 = lo); activations of tap t: slab row = local row + t
@@ -326,8 +330,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_bf16x3_kernel(ConvX3Args ax) {
   // ---- OUT == 1 (fp32 NCL, bias only): four 64-row slabs through an fp32 LDS tile
   float* Cs = (float*)lds;
   const int Lp1 = a.L + 1, ndata = a.B * Lp1;
-  for (int slab = 0; slab < 4; ++slab) {
-    if ((wn0 >> 6) == slab) {          // the waves that own rows of this 64-row slab (four of them; two in the narrow tile)
+  for (int slab = 0; slab < RT / 64; ++slab) {
+    if ((wn0 >> 6) == slab) {          // the waves that own rows of this 64-row slab (four of them; two / four in the narrow tiles)
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
@@ -764,6 +768,10 @@ extern "C" int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bi
     (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
     (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
+    (void)hipFuncSetAttribute((const void*)conv1d_bf16x3_kernel<0, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS2);
   }
   // fp32-NCL output of at most 128 channels (the pre-VQ convolution): 128-channel m-tile, no MFMA spent on padding channels
   // (option "fx_narrow" = 0 switches it off here as in the f16mx kernel); results are bit-identical to the 256-wide tile's
@@ -773,8 +781,19 @@ extern "C" int alvq_conv1d_bf16x3(const void* x, const void* wp, const float* bi
   const int forced = (int)option(OPT_FX_ROWS);
   const bool narrow = option(OPT_FX_NARROW) != 0 && (M <= 128 || (forced != 256 && a.b.rtiles * a.b.mtiles < 192) || forced == 128);
   if (narrow) a.b.mtiles = pad_to(M, 128) / 128;
+  // still fewer than ~3/4 of the CUs covered: 128-row tiles as well
+  const bool small = narrow && forced != 256 && (a.b.rtiles * a.b.mtiles < 192 || forced == 128);
+  if (small) a.b.rtiles = (int)(rows / 128);
   const dim3 grid(a.b.rtiles * a.b.mtiles), block(512);
-  if (narrow) {
+  if (small) {
+    if (y) {
+      if (KW == 3) hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 3, 1>), grid, block, X3_LDS2, s, a);
+      else hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 1, 1>), grid, block, X3_LDS2, s, a);
+    } else {
+      if (KW == 3) hipLaunchKernelGGL((conv1d_bf16x3_kernel<1, 3, 1>), grid, block, X3_LDS2, s, a);
+      else hipLaunchKernelGGL((conv1d_bf16x3_kernel<1, 1, 1>), grid, block, X3_LDS2, s, a);
+    }
+  } else if (narrow) {
     if (y) {
       if (KW == 3) hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 3, 2>), grid, block, X3_LDS2, s, a);
       else hipLaunchKernelGGL((conv1d_bf16x3_kernel<0, 1, 2>), grid, block, X3_LDS2, s, a);

@@ -84,9 +84,10 @@ def test_conv_bf16x3_epilogue_fusions():
 @pytest.mark.parametrize("B,C,M,L,KW", [(2, 1024, 128, 500, 3), (2, 1024, 64, 201, 3), (3, 64, 1024, 201, 1), (2, 500, 1024, 201, 3),
                                        (2, 24, 40, 50, 3), (5, 130, 130, 129, 1), (8, 1024, 1024, 500, 3)])
 def test_narrow_m_tile_is_bit_identical_to_the_wide_tile(B, C, M, L, KW):
-    """Round 4: outputs of at most 128 channels and problems with fewer than 192 tiles of 256 x 256 run a 128-channel m-tile
-    (option fx_narrow, default on; the pre-VQ convolution and the RIR config's layers).  Same K order per output element: the
-    fp32-NCL output and the NLC output with every epilogue fusion must equal the wide tile's BIT FOR BIT."""
+    """Round 4: outputs of at most 128 channels and problems with fewer than 192 tiles of 256 x 256 run a 128-channel m-tile,
+    on 256 or 128 rows (options fx_narrow / fx_rows; the pre-VQ convolution and the RIR config's layers).  Same K order per
+    output element: the fp32-NCL output and the NLC output with every epilogue fusion must equal the wide tile's BIT FOR BIT,
+    whichever of the three tiles the dispatch (or a forced option) picks."""
     torch.manual_seed(3)
     x, w, b = torch.randn(B, C, L), torch.randn(M, C, KW) / (C * KW) ** 0.5, torch.randn(M)
     s1, mk, post = (torch.randn(B, M, L) for _ in range(3))
@@ -94,20 +95,24 @@ def test_narrow_m_tile_is_bit_identical_to_the_wide_tile(B, C, M, L, KW):
     xn, pk = cu(x), N.pack_weight(w.cuda(), N.W_OIK, planes=2)
     ops = (cu(s1), None, cu(mk), cu(post))
     outs = {}
-    prev = N.get_option("fx_narrow")
+    prev = N.get_option("fx_narrow"), N.get_option("fx_rows")
     try:
-        for narrow in (1, 0):
-            N.set_option("fx_narrow", narrow)
+        # (fx_narrow, fx_rows): the 256 x 256 tile; the automatic choice; 128 x 128 forced; 128 channels x 256 rows where M <= 128
+        for key in ((0, 0), (1, 0), (1, 128), (1, 256)):
+            N.set_option("fx_narrow", key[0])
+            N.set_option("fx_rows", key[1])
             y, y2 = N.conv1d_bf16(xn, pk, b.cuda(), *ops, relu=True)
-            outs[narrow] = (N.conv1d_bf16(xn, pk, b.cuda(), out_ncl=True),       # the matrices only: guard rows are never written
-                            y.matrix(0).view(torch.int16).clone(), y.matrix(1).view(torch.int16).clone(),
-                            y2.matrix(0).view(torch.int16).clone(), y2.matrix(1).view(torch.int16).clone())
+            outs[key] = (N.conv1d_bf16(xn, pk, b.cuda(), out_ncl=True),       # the matrices only: guard rows are never written
+                         y.matrix(0).view(torch.int16).clone(), y.matrix(1).view(torch.int16).clone(),
+                         y2.matrix(0).view(torch.int16).clone(), y2.matrix(1).view(torch.int16).clone())
     finally:
-        N.set_option("fx_narrow", prev)
-    for a, c in zip(outs[1], outs[0]):
-        assert torch.equal(a, c)
+        N.set_option("fx_narrow", prev[0])
+        N.set_option("fx_rows", prev[1])
+    for key in ((1, 0), (1, 128), (1, 256)):
+        for a, c in zip(outs[key], outs[(0, 0)]):
+            assert torch.equal(a, c), key
     ref = F.conv1d(x, w, b, padding=KW // 2)
-    assert rel(outs[1][0], ref) < 3e-5
+    assert rel(outs[(1, 0)][0], ref) < 3e-5
 
 
 @pytest.mark.parametrize("KW", [1, 3])
