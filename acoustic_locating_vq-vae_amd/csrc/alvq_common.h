@@ -11,7 +11,7 @@ namespace alvq {
 void set_error(const char* fmt, ...);
 
 // dispatch options (api.hip): environment-initialised, run-time settable through alvq_set_option
-enum Option { OPT_WIDE_MIN_TILES, OPT_FX_ROWS, OPT_FX_NARROW, OPT_CONV_V2, OPT_CONV_K3, OPT_WGRAD_V3, OPT_COUNT };
+enum Option { OPT_WIDE_MIN_TILES, OPT_FX_ROWS, OPT_FX_NARROW, OPT_CONV_V2, OPT_CONV_K3, OPT_WGRAD_V3, OPT_VQ_REG, OPT_COUNT };
 long option(int id);
 
 inline int check_launch(const char* what) {

@@ -27,6 +27,7 @@ static const OptionSpec kSpecs[OPT_COUNT] = {
     {"conv_v2", "ALVQ_CONV_V2", 1},                   // bf16: the 256 x 256-tile kernels at all
     {"conv_k3", "ALVQ_CONV_K3", 1},                   // bf16: the shared-slab width-3 kernel (0: the generic 256 x 256 one)
     {"wgrad_v3", "ALVQ_WGRAD_V3", 3},                 // bf16 weight gradient without bias: v3 kernels for width 1 (1) / width 3 (2)
+    {"vq_reg", "ALVQ_VQ_REG", 1},                     // quantiser argmin: x rows in registers (D <= 256); 0 = the LDS-stationary kernel
 };
 static std::atomic<long> g_opt[OPT_COUNT];
 static std::atomic<int> g_opt_ready{0};

@@ -225,9 +225,10 @@ __global__ void adam_advance_kernel(float* sc, double lr, double beta1, double b
     const int f = *range_flag;
     if (f) { *range_sticky |= f; *range_flag = 0; }
   }
-  if (t < 1.0) t = 1.0;                       // the very first step was skipped: its scalars are still step 1's
-  sc[0] = (float)(lr / (1.0 - pow(beta1, t)));
-  sc[1] = (float)sqrt(1.0 - pow(beta2, t));
+  const double tt = t < 1.0 ? 1.0 : t;        // the very first step was skipped: the retry is step 1 again (t itself stays 0,
+                                              // so that the first APPLIED step is counted -- and bias-corrected -- as step 1)
+  sc[0] = (float)(lr / (1.0 - pow(beta1, tt)));
+  sc[1] = (float)sqrt(1.0 - pow(beta2, tt));
   sc[2] = (float)grad_scale;
   sc[3] = (float)t;
 }

@@ -171,6 +171,156 @@ __global__ __launch_bounds__(64 * NW, 2) void vq_argmin_f32_kernel(ArgminArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 4: the same search with the x rows of a wave held in REGISTERS (D <= 256).  The stationary block in LDS was what
+// limited the stress config (BASELINE configs[3]: 256 000 x 256 against 4 096 codes): 128 rows x 256 dims = 128 KB left room
+// for ONE workgroup per CU and a single-buffered codebook tile, so every one of its two barriers per 64 MFMAs was exposed
+// (0.55 of the fp32 MFMA peak).  A 16x16x4 MFMA takes ONE float of A per lane -- lane (li, kq) supplies x[row li][4 s + kq] --
+// so a wave's 16 rows are D / 4 registers per lane (64 at D = 256), loaded once; LDS then holds only the codebook tile,
+// double-buffered (37 KB: several workgroups per CU, one barrier per tile chunk), stored k-major ([code][kq][s]) so that a
+// lane fetches its 8 values of a chunk with two 16-byte reads instead of eight 4-byte ones (row stride 36 floats:
+// conflict-free).  Accumulation order per distance is unchanged (dims ascending, 4 per MFMA): results are bit-identical to
+// vq_argmin_f32_kernel's, and so are the indices.
+//   ND = 32-dim chunks per row (D <= 32 ND; 2, 4 or 8), RW = 16-row fragments per wave (2 where the registers allow: the
+//   codebook tile is then read half as often per row).
+constexpr int VQR_ES = 36;
+template <int ND, int RW>
+__global__ __launch_bounds__(256, (ND == 8 && RW == 1) ? 3 : 2) void vq_argmin_f32_reg_kernel(ArgminArgs a) {
+  __shared__ __attribute__((aligned(16))) float Es[2][VQ_CT * VQR_ES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const long r0 = (long)blockIdx.x * (64 * RW) + wave * (16 * RW);
+  const int D = a.D, K = a.K;
+  const bool vec = (D & 3) == 0;
+
+  float xa[RW][ND * 8];
+#pragma unroll
+  for (int f = 0; f < RW; ++f) {
+    const long row = r0 + f * 16 + li;
+    const float* xr = a.x + row * D;
+#pragma unroll
+    for (int j = 0; j < ND * 8; ++j) {
+      const int d = 4 * j + kq;
+      xa[f][j] = (row < a.N && d < D) ? xr[d] : 0.f;
+    }
+  }
+  float xn[RW][4], best[RW][4];
+  int bidx[RW][4];
+#pragma unroll
+  for (int f = 0; f < RW; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = r0 + f * 16 + kq * 4 + r;
+      xn[f][r] = row < a.N ? a.xn[row] : 0.f;
+      best[f][r] = __builtin_inff();
+      bidx[f][r] = 0x7fffffff;
+    }
+
+  // codebook staging: a chunk = 128 codes x 32 dims; thread -> (code = (tid >> 3) + 32 i, dims 4 c8 .. 4 c8 + 3), i = 0..3
+  const int c8 = tid & 7, ecode = tid >> 3;
+  f32x4 er[4];
+  auto load_e = [&](int kt, int dc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kt * VQ_CT + ecode + 32 * i, d = dc * VQ_DK + 4 * c8;
+      const float* p = a.e + (long)k * D + d;
+      if (k < K && vec && d + 3 < D) er[i] = *(const f32x4*)p;
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) er[i][q] = (k < K && d + q < D) ? p[q] : 0.f;
+      }
+    }
+  };
+  auto store_e = [&](int buf) {        // dim 4 s + kq of a chunk -> position kq * 8 + s
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Es[buf][(ecode + 32 * i) * VQR_ES + q * 8 + c8] = er[i][q];
+  };
+
+  const int nkt = (K + VQ_CT - 1) / VQ_CT;
+  load_e(0, 0);
+  store_e(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x4 acc[RW][8];
+#pragma unroll
+    for (int f = 0; f < RW; ++f)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) acc[f][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dc = 0; dc < ND; ++dc) {        // ND is even: chunk dc of every tile sits in buffer dc & 1
+      const bool more = !(kt == nkt - 1 && dc == ND - 1);
+      if (more) load_e(dc == ND - 1 ? kt + 1 : kt, dc == ND - 1 ? 0 : dc + 1);
+      const float* eb = &Es[dc & 1][li * VQR_ES + kq * 8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x4 b0[4], b1[4];
+#pragma unroll
+        for (int n4 = 0; n4 < 4; ++n4) {
+          const float* p = eb + (half * 4 + n4) * 16 * VQR_ES;
+          b0[n4] = *(const f32x4*)p;
+          b1[n4] = *(const f32x4*)(p + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int n4 = 0; n4 < 4; ++n4) {
+            const float bf = s < 4 ? b0[n4][s & 3] : b1[n4][s & 3];
+#pragma unroll
+            for (int f = 0; f < RW; ++f)
+              acc[f][half * 4 + n4] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[f][dc * 8 + s], bf, acc[f][half * 4 + n4], 0, 0, 0);
+          }
+      }
+      if (more) store_e((dc + 1) & 1);
+      __syncthreads();
+    }
+    // distances of this code tile: acc[f][ni][r] = x[row f*16 + kq*4 + r] . e[code ni*16 + li]
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      const int k = kt * VQ_CT + ni * 16 + li;
+      if (k < K) {
+        const float bn = a.en[k];
+#pragma unroll
+        for (int f = 0; f < RW; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = (xn[f][r] + bn) - 2.0f * acc[f][ni][r];
+            if (d < best[f][r]) {
+              best[f][r] = d;
+              bidx[f][r] = k;
+            }
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+    for (int f = 0; f < RW; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d2 = __shfl_xor(best[f][r], o, 64);
+        const int k2 = __shfl_xor(bidx[f][r], o, 64);
+        if (d2 < best[f][r] || (d2 == best[f][r] && k2 < bidx[f][r])) {
+          best[f][r] = d2;
+          bidx[f][r] = k2;
+        }
+      }
+  if (li == 0) {
+#pragma unroll
+    for (int f = 0; f < RW; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = r0 + f * 16 + kq * 4 + r;
+        if (row < a.N) {
+          a.idx[row] = (int64_t)(bidx[f][r] == 0x7fffffff ? 0 : bidx[f][r]);
+          if (a.min_dist) a.min_dist[row] = best[f][r];
+        }
+      }
+  }
+}
+
 // q_st = x + (E[idx] - x); per-workgroup partial of sum (E[idx]-x)^2; histogram of idx.
 __global__ __launch_bounds__(256) void vq_gather_loss_kernel(const float* x, const float* e, const int64_t* idx,
                                                              float* q_st, float* partials, int32_t* hist, long N, int K,
@@ -391,6 +541,21 @@ extern "C" int alvq_vq_argmin_f32(const float* x, const float* codebook, int64_t
   if (attr_set.need()) {
     (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)vq_argmin_f32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  // D <= 256: the x rows in registers, codebook tile double-buffered (option "vq_reg" = 0: the LDS-stationary kernel)
+  if (D <= 256 && option(OPT_VQ_REG) != 0) {
+    const int nd = D <= 64 ? 2 : (D <= 128 ? 4 : 8);
+    // two row fragments per wave (the codebook tile read half as often per row) where the registers allow (D <= 128) and the
+    // problem still gives every CU two workgroups; otherwise 64-row workgroups
+    const bool two = nd != 8 && N >= 128L * 512;
+    const int rows_wg = two ? 128 : 64;
+    const dim3 grid((unsigned)((N + rows_wg - 1) / rows_wg));
+    if (nd == 2 && two) hipLaunchKernelGGL((vq_argmin_f32_reg_kernel<2, 2>), grid, dim3(256), 0, s, a);
+    else if (nd == 2) hipLaunchKernelGGL((vq_argmin_f32_reg_kernel<2, 1>), grid, dim3(256), 0, s, a);
+    else if (nd == 4 && two) hipLaunchKernelGGL((vq_argmin_f32_reg_kernel<4, 2>), grid, dim3(256), 0, s, a);
+    else if (nd == 4) hipLaunchKernelGGL((vq_argmin_f32_reg_kernel<4, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((vq_argmin_f32_reg_kernel<8, 1>), grid, dim3(256), 0, s, a);
+    return check_launch("alvq_vq_argmin_f32");
   }
   // 8 waves (128 rows) from D = 128 up: a 4-wave workgroup would leave one wave per SIMD there, and 128-row blocks
   // halve the codebook-tile traffic per row (+7 % at the speech size)

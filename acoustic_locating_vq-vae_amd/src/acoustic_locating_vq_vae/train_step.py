@@ -142,6 +142,14 @@ class FlatAdam:
         N.adam_advance(self.scalars, self.lr, self.betas[0], self.betas[1], grad_scale,
                        prev_skip=self.b.skip_slot if self.guard else None)
 
+    def applied_steps(self):
+        """Optimiser steps actually applied so far (one host sync): the device's step number minus the step in flight if the
+        guard skipped it (its retry will carry the same number)."""
+        n = int(self.scalars[3].item())
+        if self.guard and float(self.b.skip_slot.item()) != 0.0:
+            n -= 1
+        return n
+
     def skipped_steps(self, reset=True):
         """Steps the guard skipped since the counter was last reset (one host sync).  The step in flight is counted by the
         NEXT ``prepare``."""
@@ -414,7 +422,7 @@ class Trainer:
         and the step count.  The reference only ever saves the model (``torch.save(model, ...)``), so its resumed
         runs restart Adam from zero; with this a resumed step is bitwise the step that would have come next."""
         return {"model": self.model.state_dict(), "exp_avg": self.opt.exp_avg.clone(), "exp_avg_sq": self.opt.exp_avg_sq.clone(),
-                "step": int(self.opt.scalars[3].item()),          # steps APPLIED (a skipped step does not count)
+                "step": self.opt.applied_steps(),                 # steps APPLIED (a skipped step does not count)
                 "numel": self.buffers.flat.numel(), "kind": self.kind}
 
     def load_state_dict(self, state):

@@ -49,8 +49,11 @@ const char* alvq_last_error(void);
  *   wide_min_tiles 192   bf16: 256 x 256-tile conv kernels only for problems with at least this many such tiles
  *   conv_v2 1, conv_k3 1 bf16: the 256 x 256 kernels at all / the shared-slab width-3 form
  *   wgrad_v3 3           bf16 weight gradient without bias: v3 kernels for width 1 (bit 0) / width 3 (bit 1)
- *   fx_rows 0            f16mx conv row tile: 0 automatic, 128 or 256 forced
- *   fx_narrow 1          f16mx: 128-channel m-tile for fp32-NCL outputs of <= 128 channels
+ *   fx_rows 0            f16mx / bf16x3 conv row tile: 0 automatic, 128 or 256 forced
+ *   fx_narrow 1          f16mx: 128-channel m-tile for fp32-NCL outputs of <= 128 channels; bf16x3: the 128-channel m-tiles
+ *                        (outputs of <= 128 channels, problems with fewer than 192 tiles of 256 x 256)
+ *   vq_reg 1             quantiser argmin, D <= 256: x rows in registers + double-buffered codebook tile (0: the
+ *                        LDS-stationary kernel; bit-identical results)
  * alvq_set_option returns ALVQ_EINVAL for an unknown name; alvq_get_option returns INT64_MIN. */
 int alvq_set_option(const char* name, int64_t value);
 int64_t alvq_get_option(const char* name);

@@ -263,3 +263,25 @@ def test_vq_codebook_gradient_is_atomic_free_and_reproducible(n, K, D, hot):
     acc = base.clone()
     N.vq_backward(None, dev(gl), dev(x), dev(E), idx.cuda(), beta, want_dx=False, dE_out=acc)
     assert rel(acc.double() - base.double(), want_dE) < 1e-5
+
+
+@pytest.mark.parametrize("n,K,D", [(32000, 1024, 128), (6432, 1024, 64), (777, 513, 100), (65, 16, 1), (4097, 1000, 31), (1000, 130, 200),
+                                    (129, 4096, 256), (64000, 4096, 256), (300, 77, 4), (5, 3, 255)])
+def test_vq_argmin_register_kernel_is_bit_identical_to_the_lds_kernel(n, K, D):
+    """Round 4: for D <= 256 the search keeps a wave's x rows in registers and double-buffers the codebook tile (option vq_reg,
+    default on).  Same accumulation order per distance: indices AND minimum distances must equal the LDS-stationary kernel's bit
+    for bit -- ragged row / code / dim counts, init-scale and data-scale codebooks."""
+    g = torch.Generator().manual_seed(n + K + D)
+    x = torch.randn(n, D, generator=g).cuda()
+    for scale in (0.8, 1.0 / K):
+        e = (torch.rand(K, D, generator=g) * 2 - 1).cuda() * scale
+        outs = {}
+        prev = N.get_option("vq_reg")
+        try:
+            for v in (1, 0):
+                N.set_option("vq_reg", v)
+                idx, dist = N.vq_argmin(x, e, want_dist=True)
+                outs[v] = (idx.clone(), dist.clone())
+        finally:
+            N.set_option("vq_reg", prev)
+        assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1]), (scale, int((outs[1][0] != outs[0][0]).sum()))
