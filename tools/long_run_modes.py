@@ -23,7 +23,7 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     pool = [torch.randn(B, 201, 500, device="cuda", generator=g).abs() * (1 + i % 3) for i in range(8)]
     curves = {}
-    modes = ("f32", "f32+ulp", "f16mx", "f16mx_hb", "f16mx_hd", "bf16x3", "bf16x3_hb", "bf16")
+    modes = ("f32", "f32+ulp", "x3mx_hb", "f16mx_hb", "bf16x3_hb", "bf16")
     for mode in modes:
         _ops.set_compute_dtype(mode.split("+")[0])
         torch.manual_seed(3)

@@ -40,10 +40,12 @@ def main():
             torch.cuda.synchronize()
             marks.append((s + 1, float(out[0]), float(out[1]), float(out[2]), (s + 1) * B / (time.perf_counter() - t0)))
             print("step %5d  loss %.4f  recon %.4f  perplexity %.1f  %.0f spectrograms/s" % marks[-1], flush=True)
-    flag = N.f16mx_range_flag(reset=True) if mode.startswith("f16mx") else 0
-    ok = all(np.isfinite(v[1]) for v in marks) and flag == 0
-    print("%s: %d steps at B=%d, final loss %.4f (first mark %.4f), fp16 range flag %d -> %s"
-          % (mode, steps, B, marks[-1][1], marks[0][1], flag, "OK" if ok else "FAILED"))
+    flag = N.f16mx_range_flag(reset=True) if _ops.has_fp16_range(mode) else 0
+    tr.opt.prepare(tr.grad_scale)            # the advance that counts the last step's verdict
+    skipped = tr.opt.skipped_steps()
+    ok = all(np.isfinite(v[1]) for v in marks) and flag == 0 and skipped == 0
+    print("%s: %d steps at B=%d, final loss %.4f (first mark %.4f), fp16 range flag %d, skipped steps %d -> %s"
+          % (mode, steps, B, marks[-1][1], marks[0][1], flag, skipped, "OK" if ok else "FAILED"))
     sys.exit(0 if ok else 1)
 
 
