@@ -122,6 +122,25 @@ def test_two_ranks_on_one_card_gloo():
     assert finals["1"] == finals["2"], finals            # same arithmetic whichever way the buffer is reduced
 
 
+@pytest.mark.parametrize("buckets,launch", [(1, "eager"), (2, "eager"), (1, "graph"), (2, "graph")])
+def test_a_step_saturated_on_one_rank_is_skipped_on_every_rank(buckets, launch):
+    """The skip verdict is element 0 of the flat gradient buffer and travels through the step's all-reduce: a NaN in ONE rank's
+    batch must leave the parameters of BOTH ranks untouched (and identical), count one skipped step on both, and the clean steps
+    after it must move both in lockstep -- single all-reduce and two spans (the slot belongs to the span reduced last), eager
+    and graph replay.  Two ranks sharing the card over gloo, default mode."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "helpers", "ddp_skip.py"), "x3mx_hb", str(buckets), launch]
+    p = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("DDP_SKIP ")][-1][len("DDP_SKIP "):])
+    print(json.dumps(res))
+    assert len(res) == 2
+    for r in res:
+        assert r["untouched"] and r["slot"] == 1.0 and r["identical_after_skip"], r
+        assert r["moved"] and r["identical_at_end"] and r["finite"], r
+        assert r["skipped"] == 1 and r["applied"] == (4 if launch == "eager" else 5) - 1, r      # graph: one warm-up step more
+
+
 @pytest.mark.parametrize("mode,tol,ranks", [("f32", 2e-6, 2), ("x3mx_hb", 2e-5, 2), ("f32", 2e-6, 4)])
 @pytest.mark.parametrize("buckets", [1, 2])
 def test_two_rank_steps_equal_one_rank_on_the_concatenated_batch(mode, tol, ranks, buckets, tmp_path):
