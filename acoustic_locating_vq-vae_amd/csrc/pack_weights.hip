@@ -126,23 +126,56 @@ __global__ __launch_bounds__(256) void adam_pack_batch_kernel(AdamPackBatch b) {
   const float lr_bc1 = b.sc[0], bc2_sqrt = b.sc[1], gscale = b.sc[2];
   const float beta1 = b.beta1, beta2 = b.beta2, eps = b.eps;
   const int run = 64 * KW;
+  // a row segment of the tile is 64 * KW contiguous floats: 16-byte loads / stores when every segment starts on a 16-byte
+  // boundary and the tile is full along dim1 (round 4: the scalar form ran at 3.8 TB/s); the arithmetic per element is the same
+  if (q0 + 64 <= d.dim1 && ((d.dim1 * KW) & 3) == 0) {
 #pragma unroll 2
-  for (int e = tid; e < 32 * run; e += 256) {
-    const int rr = e / run, j = e - rr * run, qq = j / KW, t = j - qq * KW;
-    float wn = 0.f;
-    if (r0 + rr < d.dim0 && q0 + qq < d.dim1) {
-      const long i = ((long)(r0 + rr) * d.dim1 + q0) * KW + j;
-      const float gr = d.g[i] * gscale;
-      const float m0 = d.m[i], v0 = d.v[i];
-      const float mm = m0 + (gr - m0) * (1.f - beta1);
-      const float vv = v0 * beta2 + (1.f - beta2) * gr * gr;
-      const float denom = sqrtf(vv) / bc2_sqrt + eps;
-      d.m[i] = mm;
-      d.v[i] = vv;
-      wn = d.w[i] - lr_bc1 * (mm / denom);
-      d.w[i] = wn;
+    for (int e4 = tid; e4 < 8 * run; e4 += 256) {
+      const int e = 4 * e4, rr = e / run, j = e - rr * run;
+      f32x4 wn = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + rr < d.dim0) {
+        const long i = ((long)(r0 + rr) * d.dim1 + q0) * KW + j;
+        const f32x4 g4 = *(const f32x4*)(d.g + i), m4 = *(const f32x4*)(d.m + i), v4 = *(const f32x4*)(d.v + i), w4 = *(const f32x4*)(d.w + i);
+        f32x4 mo, vo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float gr = g4[q] * gscale;
+          const float mm = m4[q] + (gr - m4[q]) * (1.f - beta1);
+          const float vv = v4[q] * beta2 + (1.f - beta2) * gr * gr;
+          const float denom = sqrtf(vv) / bc2_sqrt + eps;
+          mo[q] = mm;
+          vo[q] = vv;
+          wn[q] = w4[q] - lr_bc1 * (mm / denom);
+        }
+        *(f32x4*)(d.m + i) = mo;
+        *(f32x4*)(d.v + i) = vo;
+        *(f32x4*)(d.w + i) = wn;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jj = j + q, qq = jj / KW, t = jj - qq * KW;
+        tile[t][rr][qq] = wn[q];
+      }
     }
-    tile[t][rr][qq] = wn;
+  } else {
+#pragma unroll 2
+    for (int e = tid; e < 32 * run; e += 256) {
+      const int rr = e / run, j = e - rr * run, qq = j / KW, t = j - qq * KW;
+      float wn = 0.f;
+      if (r0 + rr < d.dim0 && q0 + qq < d.dim1) {
+        const long i = ((long)(r0 + rr) * d.dim1 + q0) * KW + j;
+        const float gr = d.g[i] * gscale;
+        const float m0 = d.m[i], v0 = d.v[i];
+        const float mm = m0 + (gr - m0) * (1.f - beta1);
+        const float vv = v0 * beta2 + (1.f - beta2) * gr * gr;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        d.m[i] = mm;
+        d.v[i] = vv;
+        wn = d.w[i] - lr_bc1 * (mm / denom);
+        d.w[i] = wn;
+      }
+      tile[t][rr][qq] = wn;
+    }
   }
   __syncthreads();
   if (d.oik) {                     // image[t][m = dim0][c = dim1]
