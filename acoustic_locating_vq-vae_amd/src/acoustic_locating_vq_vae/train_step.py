@@ -508,6 +508,23 @@ class Trainer:
         self._finish(early)
         return self._static_out
 
+    def evaluate(self, raw, wiener=None):
+        """The loops' validation step (train_speech.py:57-59,76-86; train_rir.py:36-40,60-70): ``model.eval()`` -- so no jitter and
+        no draw from ``np.random`` -- the same preprocessing, forward and losses, no backward, no update; the model's mode is
+        restored.  Returns (loss, recon_error, perplexity) as 0-dim device tensors.  (The reference runs it outside
+        ``torch.no_grad()`` and throws the autograd graph away; nothing is recorded here.)"""
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            if self.pack_pool is not None:
+                self.pack_pool.refresh_static()
+            with torch.no_grad(), _ops.use_pack_pool(self.pack_pool):
+                x, target = self.preprocess(raw, wiener)
+                loss, recon_error, perplexity = self.forward_loss(x, target)
+        finally:
+            self.model.train(was_training)
+        return loss.detach(), recon_error.detach(), perplexity.detach()
+
     def capture(self, raw, wiener=None, warmup=3):
         """Capture the two launch-bound parts of a step into hipGraphs (one memory pool).  Runs ``warmup`` real
         training steps first (allocator + workspaces + packed-weight pool reach steady state)."""

@@ -198,3 +198,43 @@ def test_default_mode_is_bf16x3_encoder_plus_f16mx_decoder():
         for k in (5, 6):
             rel = float((a[k] - out[md][k]).norm() / out[md][k].norm())
             assert rel < 2e-2, (md, k, rel)
+
+
+@pytest.mark.parametrize("mode", ["f32", "x3mx_hb"], indirect=True)
+def test_validation_step_matches_the_oracle_and_leaves_training_untouched(mode):
+    """train_speech.py:57-59,76-86: every 500th iteration is a validation step in model.eval() -- no jitter, no backward, no
+    update.  Trainer.evaluate: its losses equal the CPU oracle's eval-mode forward on the same weights; parameters, Adam state,
+    the device step counter and the np.random stream are untouched; the training steps around it are bit-identical to the same
+    steps without it -- eager and from the captured graph."""
+    import torch.nn.functional as F
+    from oracle import vqvae_oracle as O
+    from acoustic_locating_vq_vae.train_step import Trainer
+    finals = {}
+    for graph in (False, True):
+        for with_eval in (False, True):
+            tr = Trainer(_model(seed=5, use_jitter=True), "speech", range_check_every=0)
+            np.random.seed(21)
+            if graph:
+                tr.capture(_raw(4, 0), warmup=1)
+            tr.step(_raw(4, 1))
+            if with_eval:
+                torch.cuda.synchronize()
+                state = (tr.buffers.flat.clone(), tr.opt.exp_avg.clone(), tr.opt.scalars.clone(), np.random.get_state())
+                loss, rec, perp = tr.evaluate(_raw(3, 9))
+                torch.cuda.synchronize()
+                assert tr.model.training and torch.equal(state[0], tr.buffers.flat) and torch.equal(state[1], tr.opt.exp_avg)
+                assert torch.equal(state[2], tr.opt.scalars) and np.array_equal(state[3][1], np.random.get_state()[1])
+                # oracle: eval-mode forward (no jitter) on the same weights
+                p = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items() if "_layers." not in k or "_layers.0." in k}
+                x = O.speech_preprocess(_raw(3, 9).cpu())
+                ref = O.vqvae_forward(x, p, CFG[3], CFG[5], None)
+                want = float(F.mse_loss(ref["recon"], x) + ref["vq_loss"])
+                tol = 1e-5 if mode == "f32" else 1e-4
+                assert abs(float(loss) - want) <= tol * abs(want), (float(loss), want)
+                assert abs(float(rec) - float(F.mse_loss(ref["recon"], x))) <= tol * abs(want)
+                assert abs(float(perp) - float(ref["perplexity"])) <= 1e-4 * float(ref["perplexity"])
+            tr.step(_raw(4, 2))
+            tr.step(_raw(4, 3))
+            torch.cuda.synchronize()
+            finals[(graph, with_eval)] = tr.buffers.flat.clone()
+    assert torch.equal(finals[(False, True)], finals[(False, False)]) and torch.equal(finals[(True, True)], finals[(True, False)])
