@@ -948,19 +948,25 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     else:
         y = nlc_like(x, M)
         y2 = nlc_like(x, M) if post is not None else None
-    # same dispatch rule as alvq_conv1d_bf16: wide layers run the 256x256-tile kernel
+    # KernelTimer names follow rocprofv3's kernel names -- function plus its leading template arguments -- so that bench.py's
+    # per-kernel figures can be laid beside `rocprofv3 --kernel-trace --stats` line by line: conv1d_f16mx_kernel<OUT, KW, ...>,
+    # conv1d_bf16x3_kernel<OUT, KW, ...>, conv1d_bf16_k3_kernel<OUT, F16>, conv1d_bf16_v2_kernel<OUT, F16>,
+    # conv1d_bf16_kernel<KW, OUT, F16> (OUT: 0 = NLC output, 1 = fp32 NCL; F16: the fp16 opcodes of the bf16 kernels)
+    o_ = int(bool(out_ncl))
     if x.fmt == "f16mx":
-        family, fn = "conv1d_f16mx_kernel", lib().alvq_conv1d_f16mx
-    elif x.fmt == "f16":
-        family, fn = "conv1d_f16_kernel", lib().alvq_conv1d_f16
+        family, fn = "conv1d_f16mx_kernel<%d, %d, ...>" % (o_, KW), lib().alvq_conv1d_f16mx
     elif split:
-        family, fn = "conv1d_bf16x3_kernel", lib().alvq_conv1d_bf16x3
+        family, fn = "conv1d_bf16x3_kernel<%d, %d, ...>" % (o_, KW), lib().alvq_conv1d_bf16x3
     else:
         # mirrors the dispatch in csrc/conv1d_bf16.hip: wide layers go to the 256x256-tile kernels (k3 for width 3)
+        f16 = int(x.fmt == "f16")
         min_tiles = get_option("wide_min_tiles")
         wide = ((M + 255) // 256 * 256 - M) <= 32 and (x.rows // 256) * ((M + 255) // 256) >= min_tiles
-        family = ("conv1d_bf16_k3_kernel" if KW == 3 else "conv1d_bf16_v2_kernel") if wide else "conv1d_bf16_kernel"
-        fn = lib().alvq_conv1d_bf16
+        if wide:
+            family = ("conv1d_bf16_k3_kernel<%d, %d>" if KW == 3 else "conv1d_bf16_v2_kernel<%d, %d>") % (o_, f16)
+        else:
+            family = "conv1d_bf16_kernel<%d, %d, %d>" % (KW, o_, f16)
+        fn = lib().alvq_conv1d_f16 if f16 else lib().alvq_conv1d_bf16
     # sign bits: a ReLU'd bf16 output records them; a mask operand that carries valid bits is passed as bits
     extra = ()
     mask_ptr = _nlc_ptr(mask, x, M, "mask")
@@ -987,6 +993,15 @@ def conv1d_bf16(x, packed, bias=None, skip1=None, skip2=None, mask=None, post=No
     return (y, y2) if post is not None else y
 
 
+def _wgrad16_name(KW, with_bias, f16):
+    """rocprofv3's name of the 16-bit weight-gradient kernel a launch gets (mirrors csrc/conv1d_wgrad_bf16_v2.hip: the v3
+    kernels serve the launches without a bias gradient, option wgrad_v3)."""
+    sel = get_option("wgrad_v3")
+    if not with_bias and ((KW == 1 and sel & 1) or (KW == 3 and sel & 2)):
+        return "conv1d_wgrad_bf16_v3_kernel<%s, %d>" % ("3, 1, 2" if KW == 3 else "1, 2, 4", f16)
+    return "conv1d_wgrad_bf16_v2_kernel<%s, %d>" % ("3, 2" if KW == 3 else "1, 4", f16)
+
+
 def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, dbias_out=None, accumulate=False, defer=None):
     """dy, x: NLC.  fp32 dw in the weight's native layout (and dbias).  ``defer`` (a list; bf16 / fp16 formats, with
     ``accumulate`` into caller-owned dw_out / dbias_out): launch the contraction only and append the reduction's descriptors
@@ -1005,7 +1020,7 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
         raise RuntimeError("conv1d_wgrad_bf16: dy and x differ in format")
     extra = ()
     if dy.fmt == "f16":                  # x: fp16, or the H plane of a saved f16mx activation
-        family, fn, wsfn = "conv1d_wgrad_f16_kernel", lib().alvq_conv1d_wgrad_f16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes
+        family, fn, wsfn = _wgrad16_name(KW, want_bias, 1), lib().alvq_conv1d_wgrad_f16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes
         extra = (_sptr(dy.gscale, 1),)
     elif x.fmt == "f16mx":
         family, fn, wsfn = "conv1d_wgrad_f16mx_kernel", lib().alvq_conv1d_wgrad_f16mx, lib().alvq_conv1d_wgrad_f16mx_workspace_bytes
@@ -1013,7 +1028,7 @@ def conv1d_wgrad_bf16(dy, x, KW, w_layout=W_OIK, want_bias=False, dw_out=None, d
     elif x.planes == 2 and dy.planes == 2:
         family, fn, wsfn = "conv1d_wgrad_bf16x3_kernel", lib().alvq_conv1d_wgrad_bf16x3, lib().alvq_conv1d_wgrad_bf16x3_workspace_bytes
     else:
-        family, fn, wsfn = "conv1d_wgrad_bf16_v2_kernel", lib().alvq_conv1d_wgrad_bf16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes
+        family, fn, wsfn = _wgrad16_name(KW, want_bias, 0), lib().alvq_conv1d_wgrad_bf16, lib().alvq_conv1d_wgrad_bf16_workspace_bytes
     deferred = defer is not None and accumulate and dy.fmt in ("bf16", "f16")
     ws_ptr = arena_alloc(wsfn(x.B, C, M, x.L, KW), dev) if deferred else _workspace(wsfn(x.B, C, M, x.L, KW), dev).data_ptr()
     with _timed(family, 2.0 * x.B * x.L * M * C * KW):
@@ -1055,7 +1070,7 @@ def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=F
         ws_ptr = arena_alloc(nbytes, dev) if deferred else _workspace(nbytes, dev).data_ptr()
         acc = WGRAD_DEFER if deferred else int(bool(accumulate))
     if h16:
-        with _timed("conv1d_wgrad_f16_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):
+        with _timed(_wgrad16_name(KW, False, 1), 2.0 * n * x0.B * x0.L * M * C * KW):
             rc = lib().alvq_conv1d_wgrad_f16_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws_ptr, x0.B, C, M, x0.L, KW,
                                                    w_layout, acc, _sptr(dy0.gscale, 1), _stream())
         _check(rc, "alvq_conv1d_wgrad_f16_multi")
@@ -1076,7 +1091,7 @@ def conv1d_wgrad_bf16_multi(pairs, KW, w_layout=W_OIK, dw_out=None, accumulate=F
                                                       w_layout, int(bool(accumulate)), _stream())
         _check(rc, "alvq_conv1d_wgrad_bf16x3_multi")
         return dw_out
-    with _timed("conv1d_wgrad_bf16_v2_kernel", 2.0 * n * x0.B * x0.L * M * C * KW):
+    with _timed(_wgrad16_name(KW, False, 0), 2.0 * n * x0.B * x0.L * M * C * KW):
         rc = lib().alvq_conv1d_wgrad_bf16_multi(dys, xs, n, _ptr(dw_out, name="dw"), ws_ptr, x0.B, C, M, x0.L, KW,
                                                 w_layout, acc, _stream())
     _check(rc, "alvq_conv1d_wgrad_bf16_multi")

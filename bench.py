@@ -19,9 +19,9 @@ What the compact line holds (N=1):
   value / roofline ........ the headline mode (--dtype, default x3mx_hb: bf16x3 forward for everything the codebook indices
                             depend on, f16mx decoder forward, one 16-bit MFMA per backward product -- the fastest mode that
                             returns EVERY index of EVERY reference golden), hipGraph replay; `roofline` is KERNEL-ONLY (the
-                            conv family with the largest share of the step, live HIP events over an instrumented eager pass
-                            of the same steps) against the structural peak of that family's arithmetic AND against the
-                            hardware's dense 16-bit peak; `step_frac_of_peak` is the whole step's model FLOPs likewise
+                            convolution kernel -- named as rocprofv3 names it -- with the largest share of the step, live HIP
+                            events over an instrumented eager pass of the same steps) against the structural peak of that
+                            kernel's arithmetic AND against the hardware's dense 16-bit peak; `step_frac_of_peak` is the whole step's model FLOPs likewise
   parity_headline ......... index mismatches / rows of the headline mode on the goldens the REAL reference made: speech B = 2,
                             16, 64 (the timed workload itself) and RIR / echoed at their per-GPU batch of 32
   modes ................... spectrograms/s, ms/step, x CPU and golden index mismatches of every user-selectable mode; the
@@ -49,14 +49,16 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA 
 # MFMAs per product (hi*hi + hi*lo + lo*hi), f16mx one fp16 MFMA plus one block-scaled fp8 MFMA of the same duration, the
 # "hb" backward ONE 16-bit MFMA.  A mode's structural peak for the whole step is 2500 * flops / sum(flops_part * units_part).
 UNITS = {"x3mx_hb": (3, 2, 1), "f16mx_hb": (2, 2, 1), "bf16x3_hb": (3, 3, 1), "bf16": (1, 1, 1)}
+# keyed by the kernel FUNCTION; the timer's names carry the leading template arguments as rocprofv3 prints them
+# ("conv1d_f16mx_kernel<0, 3, ...>"): function = name up to "<"
 FAMILY_PEAK = {"conv1d_f32_kernel": F32_MFMA_PEAK_TFLOPS, "conv1d_wgrad_f32_kernel": F32_MFMA_PEAK_TFLOPS,
                "conv1d_bf16x3_kernel": BF16_MFMA_PEAK_TFLOPS / 3.0, "conv1d_wgrad_bf16x3_kernel": BF16_MFMA_PEAK_TFLOPS / 3.0,
                "conv1d_f16mx_kernel": BF16_MFMA_PEAK_TFLOPS / 2.0, "conv1d_wgrad_f16mx_kernel": BF16_MFMA_PEAK_TFLOPS / 2.0}
 FAMILY_NOTE = {157.3: "exact-fp32 MFMA 157.3", 2500.0: "dense 16-bit MFMA 2500", 2500.0 / 3: "2500/3: three bf16 MFMAs per product",
                1250.0: "2500/2: one fp16 + one equal-length block-scaled fp8 MFMA per product"}
 CONV_FAMILIES = ("conv1d_f32_kernel", "conv1d_wgrad_f32_kernel", "conv1d_bf16_k3_kernel", "conv1d_bf16_v2_kernel", "conv1d_bf16_kernel",
-                 "conv1d_wgrad_bf16_v2_kernel", "conv1d_bf16x3_kernel", "conv1d_wgrad_bf16x3_kernel", "conv1d_f16mx_kernel",
-                 "conv1d_wgrad_f16mx_kernel", "conv1d_f16_kernel", "conv1d_wgrad_f16_kernel")
+                 "conv1d_wgrad_bf16_v2_kernel", "conv1d_wgrad_bf16_v3_kernel", "conv1d_bf16x3_kernel", "conv1d_wgrad_bf16x3_kernel",
+                 "conv1d_f16mx_kernel", "conv1d_wgrad_f16mx_kernel")
 MODE_TEXT = {"x3mx_hb": "bf16x3 encoder+pre-VQ forward, f16mx decoder forward, one bf16/fp16 MFMA per backward product",
              "f16mx_hb": "f16mx forward (fp16 + block-scaled fp8 MFMA per product), one fp16 MFMA per backward product",
              "bf16x3_hb": "bf16x3 forward (three bf16 MFMAs per product), one bf16 MFMA per backward product",
@@ -310,18 +312,19 @@ def main():
         return dt, last, (timer.summary() if timer is not None else None), per_rank
 
     def roofline(summ):
-        # the dominant kernel = the conv family with the largest share of the timed region
-        fam = max((f for f in CONV_FAMILIES if f in summ), key=lambda f: summ[f][1])
+        # the dominant kernel = the convolution / weight-gradient kernel (rocprofv3 name: function + leading template arguments)
+        # with the largest share of the timed region
+        fam = max((f for f in summ if f.split("<")[0] in CONV_FAMILIES), key=lambda f: summ[f][1])
         n, secs, flops = summ[fam]
         ach = flops / secs / 1e12
-        peak = FAMILY_PEAK.get(fam, BF16_MFMA_PEAK_TFLOPS)     # the family's own arithmetic (fp16 = bf16 rate)
+        peak = FAMILY_PEAK.get(fam.split("<")[0], BF16_MFMA_PEAK_TFLOPS)     # the kernel's own arithmetic (fp16 = bf16 rate)
         traffic, source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            traffic = tj.get(fam)
+            traffic = tj.get(fam, tj.get(fam.split("<")[0]))
             source = "NOT measured in this run: profiles/traffic.json (rocprofv3 --pmc passes, tools/profile_bench.sh)"
-        return {"bound": "mfma", "scope": "kernel-only: the conv family with the largest share of the step", "kernel": fam,
+        return {"bound": "mfma", "scope": "kernel-only: the convolution kernel (rocprofv3 name) with the largest share of the step", "kernel": fam,
                 "achieved": ach, "peak": peak, "peak_is": FAMILY_NOTE.get(peak, "dense 16-bit MFMA 2500") + " TFLOP/s",
                 "unit": "TFLOP/s", "frac": ach / peak, "frac_of_dense_16bit_peak": ach / BF16_MFMA_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": source, "launches": n, "avg_launch_ms": 1e3 * secs / n,

@@ -23,6 +23,18 @@ def family(name):
     return m.group(1) if m else None
 
 
+def instantiation(name):
+    """The name bench.py's KernelTimer gives the launch: function + template arguments as rocprofv3 prints them; the split-format
+    convolutions keep their first two (OUT, KW) -- the tile variant behind them is the library's choice, not the caller's."""
+    m = re.search(r"alvq::(\w+)<([^>]*)>", name)
+    if not m:
+        return family(name)
+    args = [a.strip() for a in m.group(2).split(",")]
+    if m.group(1) in ("conv1d_f16mx_kernel", "conv1d_bf16x3_kernel"):
+        return "%s<%s, ...>" % (m.group(1), ", ".join(args[:2]))
+    return "%s<%s>" % (m.group(1), ", ".join(args))
+
+
 def pmc(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
@@ -50,6 +62,7 @@ def main(tag, stats_dir, fetch_dir, write_dir):
     fetch = pmc(_find(fetch_dir, "_counter_collection.csv"))
     write = pmc(_find(write_dir, "_counter_collection.csv"))
     per_kernel, fam = {}, collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+    inst = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
     for k in sorted(set(fetch) | set(write)):
         f, wr = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
         if family(k) is None:
@@ -58,8 +71,11 @@ def main(tag, stats_dir, fetch_dir, write_dir):
                                "WRITE_SIZE_KiB_avg": wr[1] / max(wr[0], 1)}
         a = fam[family(k)]
         a[0] += f[0]; a[1] += f[1]; a[2] += wr[0]; a[3] += wr[1]
+        if instantiation(k) != family(k):
+            a = inst[instantiation(k)]
+            a[0] += f[0]; a[1] += f[1]; a[2] += wr[0]; a[3] += wr[1]
     json.dump(per_kernel, open(os.path.join(HERE, tag + "_pmc.json"), "w"), indent=1)
-    traffic = {k: (2.0 * v[1] / max(v[0], 1) + v[3] / max(v[2], 1)) * 1024.0 for k, v in fam.items()}
+    traffic = {k: (2.0 * v[1] / max(v[0], 1) + v[3] / max(v[2], 1)) * 1024.0 for k, v in list(fam.items()) + list(inst.items())}
     tpath = os.path.join(HERE, "traffic.json")                      # merged: each dtype contributes its own families
     merged = json.load(open(tpath)) if os.path.exists(tpath) else {}
     merged.update(traffic)
