@@ -37,7 +37,7 @@ def dense(a):
 
 
 def one(mode, B, p):
-    _ops.set_compute_dtype(mode)
+    _ops.set_compute_dtype(mode, internal=True)
     m = g3_cases._build(CFG, p).train()
     x = O.speech_preprocess(torch.from_numpy(O.hashed_uniform(B * 201 * 500, 21, 2.0).reshape(B, 201, 500))).cuda()
     np.random.seed(9)
@@ -53,7 +53,7 @@ def one(mode, B, p):
 
 
 def main():
-    modes = sys.argv[1:] or ["f16mx", "bf16x3"]
+    modes = sys.argv[1:] or ["x3mx_hb", "f16mx_hb", "bf16x3_hb"]
     p = O.closed_form_params(O.vqvae_param_shapes(201, 1024, 128, 1024, 1024), 1.0, 0.5)
     for B in (2, 8, 32):
         ref_masks, ref_vals, ref_grads, ref_idx, ref_recon = one("f32", B, p)

@@ -18,7 +18,7 @@ from g3_cases import O, _build
 
 
 def main():
-    modes = sys.argv[1:] or ["f32", "bf16x3", "f16mx", "bf16"]
+    modes = sys.argv[1:] or ["f32", "x3mx_hb", "f16mx_hb", "bf16"]
     g = np.load(os.path.join(ROOT, "tests", "golden", "g3_speech_b64.npz"))
     cfg = (201, 1024, 128, 3, 1024, 0.25, 1024)
     p = O.closed_form_params(O.vqvae_param_shapes(201, 1024, 128, 1024, 1024), float(g["cb_scale"]), float(g["gain"]))
@@ -31,7 +31,7 @@ def main():
           % ({k: round(v, 1) for k, v in rho.items()}, n, gap.min()))
     zs = {}
     for mode in ["f32"] + [m for m in modes if m != "f32"]:
-        _ops.set_compute_dtype(mode)
+        _ops.set_compute_dtype(mode, internal=True)
         m = _build(cfg, p).eval()
         with torch.no_grad():
             zs[mode] = m._latent(x).double().view(-1, 128)       # rows in memory order, as the quantiser slices them
