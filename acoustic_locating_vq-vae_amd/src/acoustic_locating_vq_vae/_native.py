@@ -401,7 +401,9 @@ def vq_gather_loss(flat, codebook, idx, beta):
     K = codebook.shape[0]
     q_st = torch.empty_like(flat)
     partials = torch.empty((VQ_PARTIALS,), device=flat.device, dtype=torch.float32)
-    hist = torch.zeros((K,), device=flat.device, dtype=torch.int32)
+    hist = torch.empty((K,), device=flat.device, dtype=torch.float32)
+    fill_(hist, 0.0)                                 # the library's own fill (bit pattern 0 == int 0): no ATen op on the step path
+    hist = hist.view(torch.int32)
     out = torch.empty((2,), device=flat.device, dtype=torch.float32)
     L = lib()
     _check(L.alvq_vq_gather_loss_f32(_ptr(flat, name="x"), _ptr(codebook, name="codebook"),

@@ -368,13 +368,16 @@ class Trainer:
             # partials behind and ONE launch sums them all once the backward has been queued
             x, target = self.preprocess(raw, wiener)
             self.buffers.zero_grad()
+            if getattr(self, "_one", None) is None or self._one.device != x.device:
+                self._one = torch.ones((), device=x.device)   # the backward's root gradient, made once (autograd would fill a
+                #                                               fresh ones_like(loss) every step: an ATen launch on the step path)
             if self._buckets is None:
                 loss, recon_error, perplexity = self.forward_loss(x, target)
-                loss.backward()
+                loss.backward(self._one)
             else:
                 with _ops.latent_tap() as tap:
                     loss, recon_error, perplexity = self.forward_loss(x, target)
-                loss.backward()                              # decoder, quantiser -> early bucket + d(latent)
+                loss.backward(self._one)                     # decoder, quantiser -> early bucket + d(latent)
                 self._cut = tap[0] if tap else None
             if reductions:
                 N.wgrad_reduce_batch(reductions)
