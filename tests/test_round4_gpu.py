@@ -290,3 +290,41 @@ def test_model_level_fuzz_default_mode_against_f32(i):
             assert np.isfinite(float(loss)) and bool(torch.isfinite(tr.buffers.flat).all()) and float(tr.buffers.skip_slot) == 0.0
     finally:
         _ops.set_compute_dtype("f32")
+
+
+def test_module_api_polls_the_range_flag_and_warns(monkeypatch):
+    """The unchanged script loop (module API + torch.optim.Adam) has no Trainer to watch the fp16 range flag: the modules poll it
+    every ALVQ_RANGE_CHECK_EVERY training forwards and warn (round-3 advisor finding).  An input beyond 65 504 entering the
+    f16mx format must surface as a RuntimeWarning at the next poll -- and not in eval mode, nor in a mode without fp16 range."""
+    from acoustic_locating_vq_vae import _native as N, _ops
+    monkeypatch.setenv("ALVQ_RANGE_CHECK_EVERY", "2")
+    m = _model(use_jitter=False)
+    x = _raw(2, 1)
+    x[0, 0, 0] = 1.0e6
+    try:
+        _ops.set_compute_dtype("f16mx_hb")
+        _ops._API_FORWARDS = 0
+        N.f16mx_range_flag(reset=True)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            m(x)                                   # forward 1: raises the flag, no poll yet
+            assert not [v for v in w if "fp16 range flag" in str(v.message)]
+            m(x)                                   # forward 2: the poll
+        assert [v for v in w if issubclass(v.category, RuntimeWarning) and "fp16 range flag" in str(v.message)]
+        m.eval()
+        _ops._API_FORWARDS = 0
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for _ in range(4):
+                m(x)
+        assert not w and _ops._API_FORWARDS == 0   # evaluation passes are not counted
+        m.train()
+        _ops.set_compute_dtype("f32")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for _ in range(4):
+                m(x)
+        assert not w
+    finally:
+        _ops.set_compute_dtype("f32")
+        N.f16mx_range_flag(reset=True)
