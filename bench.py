@@ -169,6 +169,8 @@ def compact_line(d):
     if "script_loop_mode" in d:
         v = d["script_loop_mode"]
         sec["script_loop"] = {"value": _r(v["value"], 4), "vs_trainer_eager": _r(v.get("vs_trainer_eager"), 3)}
+    if "forward_only_mode" in d:
+        sec["forward_only"] = {"value": _r(d["forward_only_mode"]["value"], 4), "ms_per_batch": _r(d["forward_only_mode"]["ms_per_batch"], 4)}
     if sec:
         out["configs"] = sec
     for k in ("grad_exchange", "rccl"):
@@ -533,6 +535,26 @@ def main():
         full["trainer_eager_mode"] = {"value": te["value"], "unit": "spectrograms/s", "ms_per_step": te["ms_per_step"],
                                       "steps": s3, "dtype": args.dtype, "launch": te["launch"]}
         full["script_loop_mode"]["vs_trainer_eager"] = full["script_loop_mode"]["value"] / te["value"]
+
+        # forward only (evaluation / feature extraction: get_latent_indices + decoder, model.eval(), no autograd graph) -- what
+        # scripts/train_location.py:69-71 and the loops' validation steps run; SURVEY section 6 quotes the CPU figure for it
+        _ops.set_compute_dtype(args.dtype)
+        m3 = ConvolutionalVQVAE(*SPEECH_CFG).cuda().eval()
+        x3 = torch.randn(B, 201, 500, device="cuda")
+        with torch.no_grad():
+            for _ in range(3):
+                m3(x3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(s3):
+                m3(x3)
+            torch.cuda.synchronize()
+        e4 = time.perf_counter() - t0
+        full["forward_only_mode"] = {"value": B * s3 / e4, "unit": "spectrograms/s", "ms_per_batch": 1e3 * e4 / s3, "batch": B,
+                                     "dtype": args.dtype, "launch": "eager, module API, eval mode, torch.no_grad()",
+                                     "algorithmic_gflop_per_spectrogram": 33.61}
+        del m3, x3
+        torch.cuda.empty_cache()
 
         # BASELINE configs[3]: the VQ argmin kernel alone, codebook 4096 x 256, N = 512 * 500 rows
         n_, k_, d_ = 256000, 4096, 256
