@@ -138,10 +138,21 @@ def test_eval_mode_has_no_jitter_and_is_deterministic():
     assert rel(a, out["recon"]) < 1e-4
 
 
-def test_average_pooling_path_matches_oracle():
+@pytest.mark.parametrize("mode,tol,gtol", [("f32", 1e-4, 1e-4), ("x3mx_hb", 1e-3, 5e-2)])
+def test_average_pooling_path_matches_oracle(mode, tol, gtol):
     """encoder_average_pooling=True (convolutional_vq_vae.py:96-97; no script enables it): the latent is averaged over time
     by alvq_row_mean_f32 and its adjoint -- values and every gradient against the oracle, use_jitter=False (with jitter the
-    one-column latent raises in the reference and here alike, _ops.jitter_source_index)."""
+    one-column latent raises in the reference and here alike, _ops.jitter_source_index).  In the default mode too: the decoder
+    then runs on ONE position per sample (L = 1)."""
+    from acoustic_locating_vq_vae import _ops
+    _ops.set_compute_dtype(mode)
+    try:
+        _average_pooling_case(tol, gtol)
+    finally:
+        _ops.set_compute_dtype("f32")
+
+
+def _average_pooling_case(tol, gtol):
     torch.manual_seed(4)
     m = build((7, 16, 4, 2, 8, 0.25, 16), encoder_average_pooling=True, out_channels=3, use_jitter=False).train()
     with torch.no_grad():
@@ -155,10 +166,10 @@ def test_average_pooling_path_matches_oracle():
     vq_loss, recon, perp = m(x.cuda())
     assert recon.shape == (5, 3, 1)
     (F.mse_loss(recon, target.cuda()) + vq_loss).backward()
-    assert rel(recon, out["recon"]) < 1e-4 and rel(vq_loss, out["vq_loss"]) < 1e-5 and rel(perp, out["perplexity"]) < 1e-5
+    assert rel(recon, out["recon"]) < tol and rel(vq_loss, out["vq_loss"]) < tol / 10 and rel(perp, out["perplexity"]) < 1e-5
     named = dict(m.named_parameters())
     for k, v in p.items():
-        assert rel(named[k].grad, v.grad) < 1e-4, k
+        assert rel(named[k].grad, v.grad) < gtol, k
 
 
 def test_submodules_standalone():
