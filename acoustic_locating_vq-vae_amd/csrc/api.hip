@@ -45,7 +45,7 @@ long option(int id) {
 }
 }  // namespace alvq
 
-extern "C" const char* alvq_version(void) { return "alvq 0.3.0 (gfx950)"; }
+extern "C" const char* alvq_version(void) { return "alvq 0.4.0 (gfx950)"; }
 extern "C" const char* alvq_last_error(void) { return alvq::g_err; }
 
 extern "C" int alvq_set_option(const char* name, int64_t value) {
